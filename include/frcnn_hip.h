@@ -1,0 +1,192 @@
+/*
+ * frcnn_hip.h -- C ABI of libfrcnn_hip.so: the Faster R-CNN region-proposal and
+ * RoI hot path as hand-written HIP kernels for gfx950 (MI355X).
+ *
+ * The reference (ttjh1234/ObjectDetection) has no FFI: its boundary is the set
+ * of Python functions in Faster_RCNN/module/.  Each entry point below replaces
+ * the TensorFlow ops one of those functions runs; the citation names the
+ * reference lines it stands in for.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the comment says "host";
+ *   - boxes are float32 [ymin, xmin, ymax, xmax], normalized;
+ *   - anchor linear index idx = (y*W + x)*A + a          (module/data.py:117);
+ *   - feature maps are addressed through explicit element strides
+ *     (sb, sh, sw, sc); channels-last (sc == 1) is the fast layout;
+ *   - the caller owns inputs, outputs and workspace; the library allocates
+ *     nothing, keeps no pointer and has no global state;
+ *   - work is ordered on `stream` (a hipStream_t passed as void*); no call
+ *     synchronises the device;
+ *   - return value: FRCNN_OK or a negative FRCNN_E_* code; nothing throws.
+ *     Data-dependent failures (short sample batches) are reported on the
+ *     device in the per-image `status`/`counts` outputs, never by a sync.
+ */
+#ifndef FRCNN_HIP_H
+#define FRCNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FRCNN_OK            0
+#define FRCNN_E_BADARG     -1   /* null pointer, non-positive size, bad flag   */
+#define FRCNN_E_WORKSPACE  -2   /* workspace missing or too small              */
+#define FRCNN_E_LAUNCH     -3   /* hipGetLastError() != hipSuccess after launch */
+#define FRCNN_E_UNSUPPORTED -4  /* size beyond what the kernels are built for  */
+
+/* flag bits written by frcnn_iou_assign */
+#define FRCNN_F_VALID     1u    /* all four anchor coords strictly in (0,1)    */
+#define FRCNN_F_POSITIVE  2u    /* valid and best IoU  > pos_thr               */
+#define FRCNN_F_NEGATIVE  4u    /* valid and best IoU  < neg_thr               */
+
+/* per-image sampler status (device side) */
+#define FRCNN_S_OK          0
+#define FRCNN_S_SHORT_BATCH 1   /* fewer negatives than batch - n_pos_taken    */
+
+typedef void* frcnn_stream_t;
+
+int         frcnn_abi_version(void);
+const char* frcnn_status_string(int status);
+
+/* ---- a1: anchor grid -------------------------------------------------------
+ * Replaces make_anchor(), Faster_RCNN/module/anchor.py:10-44 (31x31x9) and
+ * shipdetection/train.py:128-162 (32x32x12).  float64 math, one cast to f32.
+ * scales/ratios are HOST arrays (n_scales*n_ratios == A <= 64).
+ * base_w/base_h: the reference divides both axes by 500 (base_w == base_h).
+ * anchors: [H*W*A*4] float32. */
+int frcnn_anchors(float* anchors, int H, int W,
+                  const double* scales, int n_scales,
+                  const double* ratios, int n_ratios,
+                  double base_w, double base_h, frcnn_stream_t stream);
+
+/* ---- a2 + first half of a3: anchors x GT IoU, argmax, flags ----------------
+ * Replaces the broadcast IoU and argmax/threshold logic of patch_batch,
+ * Faster_RCNN/module/data.py:79-110.
+ * anchors [N,4]; gt [B,G,4] (zero rows pad); outputs per image:
+ * max_iou [B,N] f32, best_gt [B,N] i32 (first maximum), flags [B,N] u8
+ * (FRCNN_F_*).  iou_full (optional, may be NULL) receives the whole [B,N,G]
+ * matrix for parity checks. */
+int frcnn_iou_assign(const float* anchors, int N, const float* gt, int B, int G,
+                     float pos_thr, float neg_thr,
+                     float* max_iou, int32_t* best_gt, uint8_t* flags,
+                     float* iou_full, frcnn_stream_t stream);
+
+/* ---- second half of a3 + a4: RPN mini-batch sampling, gather and encode ----
+ * Replaces Faster_RCNN/module/data.py:111-149: ordered compaction of the
+ * positive list and of the negative list (negatives are positions within the
+ * valid-anchor list, decoded as anchor ids -- kept on purpose, data.py:110,118),
+ * three shuffles, gathers, corner-based target encode.
+ * Shuffle = order by (key, list position).  keys_pos/keys_neg [B,N] and
+ * keys_all [B,batch] are uint32 keys per list position; pass NULL for all
+ * three to use Philox-4x32-10 counter keys from (seed, image_base + b).
+ * Outputs per image: batch_label [B,batch] f32, batch_anchor/batch_gt/
+ * batch_reg_gt [B,batch,4] f32, gt_list [B,batch] i64, batch_pos [B,batch,3]
+ * i64 (y,x,a), counts [B,4] i32 = {P, Nneg, n_pos_taken, status}.
+ * N <= 2^24, batch <= 1024. */
+int frcnn_rpn_sample(const float* anchors, int H, int W, int A,
+                     const float* gt, int B, int G,
+                     const int32_t* best_gt, const uint8_t* flags,
+                     const uint32_t* keys_pos, const uint32_t* keys_neg,
+                     const uint32_t* keys_all, uint64_t seed, int image_base,
+                     int batch, int max_pos,
+                     float* batch_label, float* batch_anchor, float* batch_gt,
+                     int64_t* gt_list, int64_t* batch_pos, float* batch_reg_gt,
+                     int32_t* counts, frcnn_stream_t stream);
+
+/* ---- a4 / a10: corner-based target encode -------------------------------------
+ * Replaces Faster_RCNN/module/data.py:143-149 (clip_wh = 0) and :252-259
+ * (clip_wh = 1: anchor width/height clipped to [1e-2,1]).  [n,4] each. */
+int frcnn_encode(const float* anchor, const float* gt, int64_t n, int clip_wh,
+                 float* target, frcnn_stream_t stream);
+
+/* ---- a5 / a12: decode deltas and clip ------------------------------------------
+ * Replaces inverse_trans(), Faster_RCNN/module/data.py:154-176 (clip_wh = 0,
+ * anchors [n_anchor,4] broadcast over B images, deltas [B,n_anchor,4]) and
+ * generate_coord(), :179-198 (clip_wh = 1, call with B = 1 and
+ * n_anchor = total boxes).  boxes [B,n_anchor,4]. */
+int frcnn_decode_clip(const float* anchors, const float* deltas, int B, int64_t n_anchor,
+                      int clip_wh, float* boxes, frcnn_stream_t stream);
+
+/* ---- a6 (first part): per-image score top-k, sorted, with fused decode ----------
+ * Replaces tf.math.top_k + index split + inverse_trans + gather_nd,
+ * Faster_RCNN/module/model.py:45-48 (= module/data.py:203-206).
+ * scores [B,N]; descending, equal scores -> lower index first (-0 == +0).
+ * top_scores [B,K] f32, top_idx [B,K] i32.  If anchors and deltas are both
+ * non-NULL, cand_boxes [B,K,4] receives the decoded+clipped box of each
+ * selected anchor (decode of the K winners only; same values as decoding all
+ * N and gathering).  1 <= K <= min(N, 16384).  No workspace. */
+int frcnn_topk(const float* scores, int B, int N, int K,
+               const float* anchors, const float* deltas,
+               float* top_scores, int32_t* top_idx, float* cand_boxes,
+               frcnn_stream_t stream);
+
+/* ---- a6 (second part): greedy NMS ------------------------------------------------
+ * Replaces tf.image.combined_non_max_suppression(boxes, scores, post_n, post_n,
+ * iou_threshold), Faster_RCNN/module/model.py:51 (= module/data.py:209), one
+ * class.  boxes [B,K,4] already in descending-score order (ties: earlier
+ * first).  Bitmask kernel (wavefront ballot) + one-wave scan per image.
+ * proposed [B,post_n,4] = kept boxes clipped to [0,1], zero padded;
+ * keep_pos [B,post_n] i32 = kept positions in 0..K-1, -1 padded (may be NULL);
+ * keep_count [B] i32 (may be NULL).
+ * workspace: frcnn_nms_workspace_bytes(B,K) bytes, 256-byte aligned. */
+size_t frcnn_nms_workspace_bytes(int B, int K);
+int frcnn_nms(const float* boxes, int B, int K, float iou_threshold, int post_n,
+              float* proposed, int32_t* keep_pos, int32_t* keep_count,
+              void* workspace, size_t workspace_bytes, frcnn_stream_t stream);
+
+/* ---- a7 + a8: fused bilinear RoI crop + max-pool, forward --------------------------
+ * Replaces tf.image.crop_and_resize(fmap, boxes, box_idx, (crop_h,crop_w)),
+ * Faster_RCNN/module/model.py:53-55, followed by MaxPool2D((pool,pool)),
+ * Faster_RCNN/module/model.py:30, without materialising the crops.
+ * fmap [B,H,W,C] through strides (elements); rois [B,R,4];
+ * out [B,R,crop_h/pool,crop_w/pool,C] contiguous.  pool in {1,2}; pool = 1
+ * gives the plain crop.  winner (may be NULL) [same shape] u8: which sample of
+ * the pool window won, row-major, first maximum. */
+int frcnn_roi_crop_pool_fwd(const float* fmap, int B, int H, int W, int C,
+                            int64_t sb, int64_t sh, int64_t sw, int64_t sc,
+                            const float* rois, int R, int crop_h, int crop_w, int pool,
+                            float* out, uint8_t* winner, frcnn_stream_t stream);
+
+/* ---- a13: adjoint of a7 + a8 ---------------------------------------------------------
+ * The reference never differentiates the crop (stop_gradient,
+ * Faster_RCNN/module/model.py:71); this is the exact adjoint, atomic-free: each
+ * feature cell is owned by one thread group which gathers its contributions in
+ * the fixed order RoI, bin, corner.  dY/winner as written by the forward;
+ * dfmap [B,H,W,C] contiguous channels-last, fully overwritten. */
+int frcnn_roi_crop_pool_bwd(const float* dY, const uint8_t* winner, const float* rois,
+                            int B, int R, int H, int W, int C,
+                            int crop_h, int crop_w, int pool,
+                            float* dfmap, frcnn_stream_t stream);
+
+/* ---- a9 + a10: proposal <-> GT labelling and target encode ------------------------------
+ * Replaces Faster_RCNN/module/data.py:215-259.  proposed [B,R,4], gt [B,G,4],
+ * gt_label_in [B,G] i64.  Outputs: p_label [B,R] i64 (bg_label = background),
+ * gt_mask [B,R] i32, gt_onehot [B,R,num_classes] f32 (may be NULL),
+ * gt_coord [B,R,4] f32, best_gt [B,R] i32 (may be NULL), max_iou [B,R] f32
+ * (may be NULL; the clipped, floored IoU the label is decided on). */
+int frcnn_label_proposals(const float* proposed, const float* gt, const int64_t* gt_label_in,
+                          int B, int R, int G, float fg_thr, float iou_floor,
+                          int bg_label, int num_classes,
+                          int64_t* p_label, int32_t* gt_mask, float* gt_onehot,
+                          float* gt_coord, int32_t* best_gt, float* max_iou,
+                          frcnn_stream_t stream);
+
+/* ---- a11: proposal sampling ---------------------------------------------------------------
+ * Replaces Faster_RCNN/module/data.py:266-316 for any B.  Per image:
+ * n_pos = min(#(p_label != bg), max_pos) shuffled positives, batch - n_pos
+ * shuffled negatives, concatenation shuffled.  Keys as in frcnn_rpn_sample
+ * (keys_pos/keys_neg [B,R], keys_all [B,batch]; all NULL -> Philox).
+ * tindex [B,batch] i64; counts [B,4] i32 = {P, Nneg, n_pos_taken, status}. */
+int frcnn_sample_proposals(const int64_t* p_label, int B, int R, int bg_label,
+                           const uint32_t* keys_pos, const uint32_t* keys_neg,
+                           const uint32_t* keys_all, uint64_t seed, int image_base,
+                           int batch, int max_pos,
+                           int64_t* tindex, int32_t* counts, frcnn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRCNN_HIP_H */

@@ -1,0 +1,327 @@
+// Fused bilinear RoI crop + max-pool (forward) and its atomic-free adjoint.
+// Sampling rule and op order of tf.image.crop_and_resize's CPU kernel:
+//   hs = ((y2-y1)*(H-1))/(ch-1);  in_y = y1*(H-1) + y*hs
+//   rows/cols whose source coordinate is outside [0, dim-1] produce 0
+//   top = TL + (TR-TL)*lx; bottom = BL + (BR-BL)*lx; out = top + (bottom-top)*ly
+// followed by the pool x pool, stride pool maximum (first maximum wins).
+// gfx950, wave64.  -ffp-contract=off.
+#include "frcnn_common.h"
+
+namespace frcnn {
+
+constexpr int ROI_MAX_CROP = 64;
+
+struct AxisGeom {
+    int lo[ROI_MAX_CROP];      // floor index
+    int hi[ROI_MAX_CROP];      // ceil index
+    float frac[ROI_MAX_CROP];  // lerp weight
+    int ok[ROI_MAX_CROP];      // 0 -> extrapolated (output 0)
+};
+
+// geometry of sample s along one axis; c1,c2 box corners, dim image size,
+// n crop size.
+__device__ __forceinline__ void axis_sample(float c1, float c2, int dim, int n, int s, int& lo,
+                                            int& hi, float& frac, int& ok) {
+    float in;
+    if (n > 1) {
+        const float scale = ((c2 - c1) * (float)(dim - 1)) / (float)(n - 1);
+        in = c1 * (float)(dim - 1) + (float)s * scale;
+    } else {
+        in = (float)(0.5 * (double)(c1 + c2) * (double)(dim - 1));
+    }
+    ok = !(in < 0.0f || in > (float)(dim - 1));
+    const float f = floorf(in), c = ceilf(in);
+    frac = in - f;
+    lo = ok ? (int)f : 0;
+    hi = ok ? (int)c : 0;
+}
+
+__device__ __forceinline__ void fill_geom(AxisGeom& gy, AxisGeom& gx, float4 box, int H, int W,
+                                          int ch, int cw) {
+    const int t = threadIdx.x;
+    if (t < ch) axis_sample(box.x, box.z, H, ch, t, gy.lo[t], gy.hi[t], gy.frac[t], gy.ok[t]);
+    if (t >= 64 && t - 64 < cw) {
+        const int s = t - 64;
+        axis_sample(box.y, box.w, W, cw, s, gx.lo[s], gx.hi[s], gx.frac[s], gx.ok[s]);
+    }
+}
+
+__device__ __forceinline__ float4 lerp4(float4 a, float4 b, float w) {
+    float4 r;
+    r.x = a.x + (b.x - a.x) * w;
+    r.y = a.y + (b.y - a.y) * w;
+    r.z = a.z + (b.z - a.z) * w;
+    r.w = a.w + (b.w - a.w) * w;
+    return r;
+}
+
+// ---- channels-last fast path: one workgroup per RoI, one float4 of channels
+// per thread, bins walked in row-major order.  Every load and store of a wave
+// is 1 KiB contiguous.
+template <int POOL>
+__global__ void __launch_bounds__(128)
+roi_fwd_cl_kernel(const float* __restrict__ fmap, int H, int W, int C, long long sb, long long sh,
+                  long long sw, const float4* __restrict__ rois, int R, int ch, int cw,
+                  float* __restrict__ out, uint8_t* __restrict__ winner) {
+    __shared__ AxisGeom gy, gx;
+    const int r = blockIdx.x, b = blockIdx.y;
+    const float4 box = rois[(size_t)b * R + r];
+    fill_geom(gy, gx, box, H, W, ch, cw);
+    __syncthreads();
+    const int ph = ch / POOL, pw = cw / POOL;
+    const float* img = fmap + (size_t)b * sb;
+    const size_t obase = ((size_t)b * R + r) * (size_t)(ph * pw) * C;
+    const int C4 = C >> 2;
+    for (int c4 = threadIdx.x; c4 < C4; c4 += blockDim.x) {
+        const float* chan = img + c4 * 4;
+        for (int p = 0; p < ph; ++p) {
+            for (int q = 0; q < pw; ++q) {
+                float4 best = make_float4(0.f, 0.f, 0.f, 0.f);
+                uchar4 arg = make_uchar4(0, 0, 0, 0);
+#pragma unroll
+                for (int k = 0; k < POOL * POOL; ++k) {
+                    const int sy = p * POOL + k / POOL, sx = q * POOL + k % POOL;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (gy.ok[sy] && gx.ok[sx]) {          // block-uniform
+                        const float* rt = chan + (size_t)gy.lo[sy] * sh;
+                        const float* rb = chan + (size_t)gy.hi[sy] * sh;
+                        const size_t ol = (size_t)gx.lo[sx] * sw, orr = (size_t)gx.hi[sx] * sw;
+                        const float4 tl = *reinterpret_cast<const float4*>(rt + ol);
+                        const float4 tr = *reinterpret_cast<const float4*>(rt + orr);
+                        const float4 bl = *reinterpret_cast<const float4*>(rb + ol);
+                        const float4 br = *reinterpret_cast<const float4*>(rb + orr);
+                        const float lx = gx.frac[sx], ly = gy.frac[sy];
+                        const float4 top = lerp4(tl, tr, lx);
+                        const float4 bot = lerp4(bl, br, lx);
+                        v = lerp4(top, bot, ly);
+                    }
+                    if (k == 0) {
+                        best = v;
+                    } else {
+                        if (v.x > best.x) { best.x = v.x; arg.x = k; }
+                        if (v.y > best.y) { best.y = v.y; arg.y = k; }
+                        if (v.z > best.z) { best.z = v.z; arg.z = k; }
+                        if (v.w > best.w) { best.w = v.w; arg.w = k; }
+                    }
+                }
+                const size_t o = obase + (size_t)(p * pw + q) * C + c4 * 4;
+                *reinterpret_cast<float4*>(out + o) = best;
+                if (winner) *reinterpret_cast<uchar4*>(winner + o) = arg;
+            }
+        }
+    }
+}
+
+// ---- any-stride fallback: one thread per channel.
+template <int POOL>
+__global__ void __launch_bounds__(128)
+roi_fwd_generic_kernel(const float* __restrict__ fmap, int H, int W, int C, long long sb,
+                       long long sh, long long sw, long long sc, const float4* __restrict__ rois,
+                       int R, int ch, int cw, float* __restrict__ out,
+                       uint8_t* __restrict__ winner) {
+    __shared__ AxisGeom gy, gx;
+    const int r = blockIdx.x, b = blockIdx.y;
+    const float4 box = rois[(size_t)b * R + r];
+    fill_geom(gy, gx, box, H, W, ch, cw);
+    __syncthreads();
+    const int ph = ch / POOL, pw = cw / POOL;
+    const float* img = fmap + (size_t)b * sb;
+    const size_t obase = ((size_t)b * R + r) * (size_t)(ph * pw) * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float* chan = img + (size_t)c * sc;
+        for (int bin = 0; bin < ph * pw; ++bin) {
+            const int p = bin / pw, q = bin % pw;
+            float best = 0.f;
+            uint8_t arg = 0;
+            for (int k = 0; k < POOL * POOL; ++k) {
+                const int sy = p * POOL + k / POOL, sx = q * POOL + k % POOL;
+                float v = 0.f;
+                if (gy.ok[sy] && gx.ok[sx]) {
+                    const float* rt = chan + (size_t)gy.lo[sy] * sh;
+                    const float* rb = chan + (size_t)gy.hi[sy] * sh;
+                    const size_t ol = (size_t)gx.lo[sx] * sw, orr = (size_t)gx.hi[sx] * sw;
+                    const float tl = rt[ol], tr = rt[orr], bl = rb[ol], br = rb[orr];
+                    const float lx = gx.frac[sx], ly = gy.frac[sy];
+                    const float top = tl + (tr - tl) * lx;
+                    const float bot = bl + (br - bl) * lx;
+                    v = top + (bot - top) * ly;
+                }
+                if (k == 0 || v > best) { best = v; arg = (uint8_t)k; }
+            }
+            const size_t o = obase + (size_t)bin * C + c;
+            out[o] = best;
+            if (winner) winner[o] = arg;
+        }
+    }
+}
+
+// ---- backward: gather formulation.  Workgroup = one feature cell (b,y,x);
+// thread = float4 of channels.  Every RoI of the image is visited in order;
+// for each, the (at most a few) samples whose bilinear footprint touches the
+// cell are found from the axis geometry, and the winner byte decides whether
+// the bin's gradient flows through that sample.  Summation order per cell:
+// RoI, bin (row-major), corner TL,TR,BL,BR.
+template <int POOL>
+__global__ void __launch_bounds__(128)
+roi_bwd_cl_kernel(const float* __restrict__ dY, const uint8_t* __restrict__ winner,
+                  const float4* __restrict__ rois, int R, int H, int W, int C, int ch, int cw,
+                  float* __restrict__ dfmap) {
+    __shared__ int s_sy[ROI_MAX_CROP], s_sx[ROI_MAX_CROP];
+    __shared__ int s_ny, s_nx;
+    const int x = blockIdx.x, y = blockIdx.y, b = blockIdx.z;
+    const int ph = ch / POOL, pw = cw / POOL;
+    const int C4 = C >> 2;
+    // per-thread accumulators: this kernel supports C4 <= 4 * blockDim
+    float4 acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = 0; r < R; ++r) {
+        const float4 box = rois[(size_t)b * R + r];
+        __syncthreads();
+        // sample rows / cols of this RoI that touch (y, x): first wave scans rows,
+        // second wave scans cols, ordered compaction by ballot.
+        {
+            const int t = threadIdx.x;
+            if (t < 64) {
+                int lo = 0, hi = 0, ok = 0; float fr = 0.f;
+                if (t < ch) axis_sample(box.x, box.z, H, ch, t, lo, hi, fr, ok);
+                const bool hit = t < ch && ok && (lo == y || hi == y);
+                const unsigned long long m = __ballot(hit);
+                if (hit) s_sy[__popcll(m & lanemask_lt())] = t;
+                if (t == 0) s_ny = __popcll(m);
+            } else {
+                const int s = t - 64;
+                int lo = 0, hi = 0, ok = 0; float fr = 0.f;
+                if (s < cw) axis_sample(box.y, box.w, W, cw, s, lo, hi, fr, ok);
+                const bool hit = s < cw && ok && (lo == x || hi == x);
+                const unsigned long long m = __ballot(hit);
+                if (hit) s_sx[__popcll(m & lanemask_lt())] = s;
+                if (s == 0) s_nx = __popcll(m);
+            }
+        }
+        __syncthreads();
+        const int ny = s_ny, nx = s_nx;
+        if (ny == 0 || nx == 0) continue;                 // block-uniform
+        const size_t rbase = ((size_t)b * R + r) * (size_t)(ph * pw) * C;
+        for (int a = 0; a < ny; ++a) {
+            const int sy = s_sy[a];
+            int ylo, yhi, yok; float ly;
+            axis_sample(box.x, box.z, H, ch, sy, ylo, yhi, ly, yok);
+            for (int e = 0; e < nx; ++e) {
+                const int sx = s_sx[e];
+                int xlo, xhi, xok; float lx;
+                axis_sample(box.y, box.w, W, cw, sx, xlo, xhi, lx, xok);
+                const int p = sy / POOL, q = sx / POOL;
+                const int k = (sy % POOL) * POOL + (sx % POOL);
+                const size_t o = rbase + (size_t)(p * pw + q) * C;
+                const float wt = 1.0f - ly, wb = ly, wl = 1.0f - lx, wr = lx;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int c4 = threadIdx.x + u * 128;
+                    if (c4 >= C4) break;
+                    uchar4 wv = make_uchar4(0, 0, 0, 0);
+                    if (POOL > 1) wv = *reinterpret_cast<const uchar4*>(winner + o + c4 * 4);
+                    const float4 g = *reinterpret_cast<const float4*>(dY + o + c4 * 4);
+                    const bool mx = wv.x == k, my = wv.y == k, mz = wv.z == k, mw = wv.w == k;
+                    float4 dtop, dbot;
+                    dtop.x = wt * g.x; dtop.y = wt * g.y; dtop.z = wt * g.z; dtop.w = wt * g.w;
+                    dbot.x = wb * g.x; dbot.y = wb * g.y; dbot.z = wb * g.z; dbot.w = wb * g.w;
+                    // corners in the order TL, TR, BL, BR; a cell can be several of them
+                    if (ylo == y && xlo == x) {
+                        if (mx) acc[u].x += wl * dtop.x; if (my) acc[u].y += wl * dtop.y;
+                        if (mz) acc[u].z += wl * dtop.z; if (mw) acc[u].w += wl * dtop.w;
+                    }
+                    if (ylo == y && xhi == x) {
+                        if (mx) acc[u].x += wr * dtop.x; if (my) acc[u].y += wr * dtop.y;
+                        if (mz) acc[u].z += wr * dtop.z; if (mw) acc[u].w += wr * dtop.w;
+                    }
+                    if (yhi == y && xlo == x) {
+                        if (mx) acc[u].x += wl * dbot.x; if (my) acc[u].y += wl * dbot.y;
+                        if (mz) acc[u].z += wl * dbot.z; if (mw) acc[u].w += wl * dbot.w;
+                    }
+                    if (yhi == y && xhi == x) {
+                        if (mx) acc[u].x += wr * dbot.x; if (my) acc[u].y += wr * dbot.y;
+                        if (mz) acc[u].z += wr * dbot.z; if (mw) acc[u].w += wr * dbot.w;
+                    }
+                }
+            }
+        }
+    }
+    float* dst = dfmap + (((size_t)b * H + y) * W + x) * C;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int c4 = threadIdx.x + u * 128;
+        if (c4 < C4) *reinterpret_cast<float4*>(dst + c4 * 4) = acc[u];
+    }
+}
+
+}  // namespace frcnn
+
+using namespace frcnn;
+
+extern "C" int frcnn_roi_crop_pool_fwd(const float* fmap, int B, int H, int W, int C, int64_t sb,
+                                       int64_t sh, int64_t sw, int64_t sc, const float* rois,
+                                       int R, int crop_h, int crop_w, int pool, float* out,
+                                       uint8_t* winner, frcnn_stream_t stream) {
+    if (!fmap || !rois || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || R <= 0 ||
+        crop_h <= 0 || crop_w <= 0)
+        return FRCNN_E_BADARG;
+    if (pool != 1 && pool != 2) return FRCNN_E_BADARG;
+    if (crop_h % pool || crop_w % pool) return FRCNN_E_BADARG;
+    if (crop_h > ROI_MAX_CROP || crop_w > ROI_MAX_CROP || B > 65535) return FRCNN_E_UNSUPPORTED;
+    const bool fast = sc == 1 && (C % 4) == 0 && (sb % 4) == 0 && (sh % 4) == 0 && (sw % 4) == 0 &&
+                      (reinterpret_cast<uintptr_t>(fmap) % 16) == 0 &&
+                      (reinterpret_cast<uintptr_t>(out) % 16) == 0 &&
+                      (!winner || (reinterpret_cast<uintptr_t>(winner) % 4) == 0);
+    const dim3 grid(R, B), block(128);
+    const float4* rb = reinterpret_cast<const float4*>(rois);
+    hipStream_t st = (hipStream_t)stream;
+    if (fast) {
+        if (pool == 2)
+            hipLaunchKernelGGL(roi_fwd_cl_kernel<2>, grid, block, 0, st, fmap, H, W, C,
+                               (long long)sb, (long long)sh, (long long)sw, rb, R, crop_h, crop_w,
+                               out, winner);
+        else
+            hipLaunchKernelGGL(roi_fwd_cl_kernel<1>, grid, block, 0, st, fmap, H, W, C,
+                               (long long)sb, (long long)sh, (long long)sw, rb, R, crop_h, crop_w,
+                               out, winner);
+    } else {
+        if (pool == 2)
+            hipLaunchKernelGGL(roi_fwd_generic_kernel<2>, grid, block, 0, st, fmap, H, W, C,
+                               (long long)sb, (long long)sh, (long long)sw, (long long)sc, rb, R,
+                               crop_h, crop_w, out, winner);
+        else
+            hipLaunchKernelGGL(roi_fwd_generic_kernel<1>, grid, block, 0, st, fmap, H, W, C,
+                               (long long)sb, (long long)sh, (long long)sw, (long long)sc, rb, R,
+                               crop_h, crop_w, out, winner);
+    }
+    FRCNN_LAUNCH_CHECK();
+    return FRCNN_OK;
+}
+
+extern "C" int frcnn_roi_crop_pool_bwd(const float* dY, const uint8_t* winner, const float* rois,
+                                       int B, int R, int H, int W, int C, int crop_h, int crop_w,
+                                       int pool, float* dfmap, frcnn_stream_t stream) {
+    if (!dY || !rois || !dfmap || B <= 0 || R <= 0 || H <= 0 || W <= 0 || C <= 0 || crop_h <= 0 ||
+        crop_w <= 0)
+        return FRCNN_E_BADARG;
+    if (pool != 1 && pool != 2) return FRCNN_E_BADARG;
+    if (pool == 2 && !winner) return FRCNN_E_BADARG;
+    if (crop_h % pool || crop_w % pool) return FRCNN_E_BADARG;
+    if (crop_h > ROI_MAX_CROP || crop_w > ROI_MAX_CROP) return FRCNN_E_UNSUPPORTED;
+    if ((C % 4) != 0 || C > 4 * 4 * 128 || H > 65535 || B > 65535) return FRCNN_E_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(dY) % 16) || (reinterpret_cast<uintptr_t>(dfmap) % 16) ||
+        (winner && (reinterpret_cast<uintptr_t>(winner) % 4)))
+        return FRCNN_E_BADARG;
+    const dim3 grid(W, H, B), block(128);
+    const float4* rb = reinterpret_cast<const float4*>(rois);
+    hipStream_t st = (hipStream_t)stream;
+    if (pool == 2)
+        hipLaunchKernelGGL(roi_bwd_cl_kernel<2>, grid, block, 0, st, dY, winner, rb, R, H, W, C,
+                           crop_h, crop_w, dfmap);
+    else
+        hipLaunchKernelGGL(roi_bwd_cl_kernel<1>, grid, block, 0, st, dY, winner, rb, R, H, W, C,
+                           crop_h, crop_w, dfmap);
+    FRCNN_LAUNCH_CHECK();
+    return FRCNN_OK;
+}

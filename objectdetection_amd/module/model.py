@@ -1,0 +1,46 @@
+"""process_fmap and the head's RoI max-pool -- counterparts of
+Faster_RCNN/module/model.py:43-57 and :30."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .. import ops
+from ..config import PathConfig, REFERENCE
+
+
+def propose(score: torch.Tensor, coord: torch.Tensor, anchor_box: torch.Tensor,
+            cfg: PathConfig = REFERENCE, workspace: Optional[torch.Tensor] = None):
+    """Proposal creator (module/model.py:44-52): top-k -> decode -> NMS.
+    Returns dict(proposed [B,post_n,4], keep_pos, counts, top_scores, top_idx, cand)."""
+    B = score.shape[0]
+    a = anchor_box.reshape(-1, 4)
+    N = a.shape[0]
+    vals, idx, cand = ops.topk(score.reshape(B, N), cfg.pre_k, a, coord.reshape(B, N, 4))
+    proposed, keep, count = ops.nms(cand, cfg.nms_thr, cfg.post_n, workspace)
+    return dict(proposed=proposed, keep_pos=keep, counts=count, top_scores=vals, top_idx=idx,
+                cand=cand)
+
+
+def process_fmap(fmap: torch.Tensor, score: torch.Tensor, coord: torch.Tensor,
+                 anchor_box: torch.Tensor, cfg: PathConfig = REFERENCE, fuse_pool: bool = False,
+                 workspace: Optional[torch.Tensor] = None):
+    """Counterpart of module/model.py:43-57.
+
+    fmap [B,H,W,C] (NHWC, as the reference's block5_conv3 output), score
+    [B,H,W,A], coord [B,H,W,4A], anchor_box [H,W,A,4].  Returns (crop_fmap,
+    proposed) with crop_fmap [B,post_n,14,14,C] like the reference, or -- with
+    fuse_pool=True -- the pooled [B,post_n,7,7,C] tensor that the head's first
+    layer (module/model.py:30) would make of it.
+    """
+    pr = propose(score, coord, anchor_box, cfg, workspace)
+    pool = cfg.pool if fuse_pool else 1
+    crop_fmap, _ = ops.roi_crop_pool_fwd(fmap, pr["proposed"], cfg.crop, pool)
+    return crop_fmap, pr["proposed"]
+
+
+def roi_pool(fmap: torch.Tensor, proposed: torch.Tensor, cfg: PathConfig = REFERENCE,
+             want_winner: bool = False):
+    """crop_and_resize (module/model.py:54) + MaxPool2D (module/model.py:30) in one kernel."""
+    return ops.roi_crop_pool_fwd(fmap, proposed, cfg.crop, cfg.pool, want_winner)

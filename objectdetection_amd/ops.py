@@ -1,0 +1,282 @@
+"""torch.Tensor front-end of the C ABI: one function per entry point.
+
+PyTorch supplies device memory and the current HIP stream only; every
+computation happens in libfrcnn_hip.so.  Tensors must live on a ROCm device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import lib, check
+
+__all__ = [
+    "anchors", "iou_assign", "rpn_sample", "encode", "decode_clip", "topk", "nms",
+    "nms_workspace_bytes", "roi_crop_pool_fwd", "roi_crop_pool_bwd", "label_proposals",
+    "sample_proposals",
+]
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _dev(t: torch.Tensor, name: str, dtype: torch.dtype) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: must be on a ROCm device (the HIP kernels are the only path)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t
+
+
+def _cont(t: torch.Tensor, name: str, dtype: torch.dtype) -> torch.Tensor:
+    return _dev(t, name, dtype).contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def anchors(H: int, W: int, scales: Sequence[float], ratios: Sequence[float], base_w: float = 500.0,
+            base_h: Optional[float] = None, device="cuda") -> torch.Tensor:
+    """[H,W,A,4] float32 anchor grid (frcnn_anchors)."""
+    base_h = base_w if base_h is None else base_h
+    A = len(scales) * len(ratios)
+    out = torch.empty((H, W, A, 4), dtype=torch.float32, device=device)
+    sc = (C.c_double * len(scales))(*[float(s) for s in scales])
+    rt = (C.c_double * len(ratios))(*[float(r) for r in ratios])
+    with torch.cuda.device(out.device):
+        check("frcnn_anchors", lib.frcnn_anchors(_ptr(out), H, W, sc, len(scales), rt, len(ratios),
+                                                 float(base_w), float(base_h), _stream(out)))
+    return out
+
+
+def iou_assign(anchor_flat: torch.Tensor, gt: torch.Tensor, pos_thr: float = 0.3,
+               neg_thr: float = 0.3, want_iou: bool = False):
+    """anchors [N,4], gt [B,G,4] -> max_iou [B,N], best_gt [B,N] i32, flags [B,N] u8, iou|None."""
+    a = _cont(anchor_flat, "anchors", torch.float32).reshape(-1, 4)
+    g = _cont(gt, "gt", torch.float32)
+    if g.dim() != 3 or g.shape[-1] != 4:
+        raise ValueError("gt must be [B,G,4]")
+    B, G = g.shape[0], g.shape[1]
+    N = a.shape[0]
+    max_iou = torch.empty((B, N), dtype=torch.float32, device=a.device)
+    best = torch.empty((B, N), dtype=torch.int32, device=a.device)
+    flags = torch.empty((B, N), dtype=torch.uint8, device=a.device)
+    full = torch.empty((B, N, G), dtype=torch.float32, device=a.device) if want_iou else None
+    with torch.cuda.device(a.device):
+        check("frcnn_iou_assign", lib.frcnn_iou_assign(_ptr(a), N, _ptr(g), B, G, pos_thr, neg_thr,
+                                                       _ptr(max_iou), _ptr(best), _ptr(flags),
+                                                       _ptr(full), _stream(a)))
+    return max_iou, best, flags, full
+
+
+def _keys(keys, B, n_list, batch, device):
+    if keys is None:
+        return None, None, None
+    def as_i32(t, name, cols):
+        if isinstance(t, torch.Tensor) and t.dtype == torch.uint32:
+            t = t.view(torch.int32)
+        return _cont(t, name, torch.int32).reshape(B, cols)
+
+    kp, kn, ka = keys
+    return (as_i32(kp, "keys_pos", n_list), as_i32(kn, "keys_neg", n_list),
+            as_i32(ka, "keys_all", batch))
+
+
+def rpn_sample(anchor_box: torch.Tensor, gt: torch.Tensor, best_gt: torch.Tensor,
+               flags: torch.Tensor, keys=None, seed: int = 0, image_base: int = 0,
+               batch: int = 256, max_pos: int = 128):
+    """RPN mini-batch (frcnn_rpn_sample).  anchor_box [H,W,A,4]; gt [B,G,4].
+
+    keys = (keys_pos [B,N], keys_neg [B,N], keys_all [B,batch]) as int32 tensors
+    holding uint32 bit patterns, or None for counter keys from `seed`.
+    Returns dict(label, anchor, gt, gt_list, pos, reg, counts)."""
+    a = _cont(anchor_box, "anchor_box", torch.float32)
+    H, W, A = a.shape[0], a.shape[1], a.shape[2]
+    N = H * W * A
+    g = _cont(gt, "gt", torch.float32)
+    B, G = g.shape[0], g.shape[1]
+    bg = _cont(best_gt, "best_gt", torch.int32).reshape(B, N)
+    fl = _cont(flags, "flags", torch.uint8).reshape(B, N)
+    kp, kn, ka = _keys(keys, B, N, batch, a.device)
+    dev = a.device
+    out = dict(
+        label=torch.empty((B, batch), dtype=torch.float32, device=dev),
+        anchor=torch.empty((B, batch, 4), dtype=torch.float32, device=dev),
+        gt=torch.empty((B, batch, 4), dtype=torch.float32, device=dev),
+        gt_list=torch.empty((B, batch), dtype=torch.int64, device=dev),
+        pos=torch.empty((B, batch, 3), dtype=torch.int64, device=dev),
+        reg=torch.empty((B, batch, 4), dtype=torch.float32, device=dev),
+        counts=torch.empty((B, 4), dtype=torch.int32, device=dev),
+    )
+    with torch.cuda.device(dev):
+        check("frcnn_rpn_sample", lib.frcnn_rpn_sample(
+            _ptr(a), H, W, A, _ptr(g), B, G, _ptr(bg), _ptr(fl), _ptr(kp), _ptr(kn), _ptr(ka),
+            seed & 0xFFFFFFFFFFFFFFFF, image_base, batch, max_pos, _ptr(out["label"]),
+            _ptr(out["anchor"]), _ptr(out["gt"]), _ptr(out["gt_list"]), _ptr(out["pos"]),
+            _ptr(out["reg"]), _ptr(out["counts"]), _stream(a)))
+    return out
+
+
+def encode(anchor: torch.Tensor, gt: torch.Tensor, clip_wh: bool) -> torch.Tensor:
+    a = _cont(anchor, "anchor", torch.float32)
+    g = _cont(gt, "gt", torch.float32)
+    if a.shape != g.shape or a.shape[-1] != 4:
+        raise ValueError("anchor and gt must have the same [...,4] shape")
+    out = torch.empty_like(a)
+    n = a.numel() // 4
+    if n:
+        with torch.cuda.device(a.device):
+            check("frcnn_encode", lib.frcnn_encode(_ptr(a), _ptr(g), n, int(clip_wh), _ptr(out),
+                                                   _stream(a)))
+    return out
+
+
+def decode_clip(anchor_flat: torch.Tensor, deltas: torch.Tensor, clip_wh: bool) -> torch.Tensor:
+    """anchors [n,4] broadcast over deltas [B,n,4] -> boxes [B,n,4]."""
+    a = _cont(anchor_flat, "anchors", torch.float32).reshape(-1, 4)
+    d = _cont(deltas, "deltas", torch.float32)
+    n = a.shape[0]
+    d = d.reshape(-1, n, 4)
+    out = torch.empty_like(d)
+    with torch.cuda.device(a.device):
+        check("frcnn_decode_clip", lib.frcnn_decode_clip(_ptr(a), _ptr(d), d.shape[0], n,
+                                                         int(clip_wh), _ptr(out), _stream(a)))
+    return out
+
+
+def topk(scores: torch.Tensor, k: int, anchor_flat: Optional[torch.Tensor] = None,
+         deltas: Optional[torch.Tensor] = None):
+    """scores [B,N] -> (values [B,k], idx [B,k] i32, cand_boxes [B,k,4] | None)."""
+    s = _cont(scores, "scores", torch.float32)
+    if s.dim() != 2:
+        raise ValueError("scores must be [B,N]")
+    B, N = s.shape
+    vals = torch.empty((B, k), dtype=torch.float32, device=s.device)
+    idx = torch.empty((B, k), dtype=torch.int32, device=s.device)
+    a = d = cand = None
+    if anchor_flat is not None:
+        a = _cont(anchor_flat, "anchors", torch.float32).reshape(-1, 4)
+        d = _cont(deltas, "deltas", torch.float32).reshape(B, -1, 4)
+        if a.shape[0] != N or d.shape[1] != N:
+            raise ValueError("anchors / deltas do not match scores")
+        cand = torch.empty((B, k, 4), dtype=torch.float32, device=s.device)
+    with torch.cuda.device(s.device):
+        check("frcnn_topk", lib.frcnn_topk(_ptr(s), B, N, k, _ptr(a), _ptr(d), _ptr(vals),
+                                           _ptr(idx), _ptr(cand), _stream(s)))
+    return vals, idx, cand
+
+
+def nms_workspace_bytes(B: int, K: int) -> int:
+    return int(lib.frcnn_nms_workspace_bytes(B, K))
+
+
+def nms(boxes: torch.Tensor, iou_threshold: float, post_n: int,
+        workspace: Optional[torch.Tensor] = None):
+    """boxes [B,K,4] score-sorted -> (proposed [B,post_n,4], keep_pos [B,post_n] i32, count [B])."""
+    b = _cont(boxes, "boxes", torch.float32)
+    if b.dim() != 3 or b.shape[-1] != 4:
+        raise ValueError("boxes must be [B,K,4]")
+    B, K = b.shape[0], b.shape[1]
+    need = nms_workspace_bytes(B, K)
+    if workspace is None:
+        workspace = torch.empty(need, dtype=torch.uint8, device=b.device)
+    proposed = torch.empty((B, post_n, 4), dtype=torch.float32, device=b.device)
+    keep = torch.empty((B, post_n), dtype=torch.int32, device=b.device)
+    count = torch.empty((B,), dtype=torch.int32, device=b.device)
+    with torch.cuda.device(b.device):
+        check("frcnn_nms", lib.frcnn_nms(_ptr(b), B, K, iou_threshold, post_n, _ptr(proposed),
+                                         _ptr(keep), _ptr(count), _ptr(workspace),
+                                         workspace.numel() * workspace.element_size(), _stream(b)))
+    return proposed, keep, count
+
+
+def roi_crop_pool_fwd(fmap: torch.Tensor, rois: torch.Tensor, crop: Tuple[int, int] = (14, 14),
+                      pool: int = 2, want_winner: bool = False, out: Optional[torch.Tensor] = None):
+    """fmap [B,H,W,C] (any strides; channels-last is the fast layout), rois [B,R,4]
+    -> pooled [B,R,crop_h/pool,crop_w/pool,C] (+ winner u8)."""
+    f = _dev(fmap, "fmap", torch.float32)
+    if f.dim() != 4:
+        raise ValueError("fmap must be [B,H,W,C]")
+    r = _cont(rois, "rois", torch.float32)
+    B, H, W, Cc = f.shape
+    if r.dim() != 3 or r.shape[0] != B or r.shape[2] != 4:
+        raise ValueError("rois must be [B,R,4]")
+    R = r.shape[1]
+    ph, pw = crop[0] // pool, crop[1] // pool
+    if out is None:
+        out = torch.empty((B, R, ph, pw, Cc), dtype=torch.float32, device=f.device)
+    else:
+        _dev(out, "out", torch.float32)
+        if tuple(out.shape) != (B, R, ph, pw, Cc) or not out.is_contiguous():
+            raise ValueError("out has the wrong shape or is not contiguous")
+    win = torch.empty((B, R, ph, pw, Cc), dtype=torch.uint8, device=f.device) if want_winner else None
+    sb, sh, sw, sc = f.stride()
+    with torch.cuda.device(f.device):
+        check("frcnn_roi_crop_pool_fwd", lib.frcnn_roi_crop_pool_fwd(
+            _ptr(f), B, H, W, Cc, sb, sh, sw, sc, _ptr(r), R, crop[0], crop[1], pool, _ptr(out),
+            _ptr(win), _stream(f)))
+    return out, win
+
+
+def roi_crop_pool_bwd(dY: torch.Tensor, winner: Optional[torch.Tensor], rois: torch.Tensor,
+                      fmap_shape: Tuple[int, int, int, int], crop: Tuple[int, int] = (14, 14),
+                      pool: int = 2) -> torch.Tensor:
+    g = _cont(dY, "dY", torch.float32)
+    r = _cont(rois, "rois", torch.float32)
+    w = _cont(winner, "winner", torch.uint8) if winner is not None else None
+    B, H, W, Cc = fmap_shape
+    R = r.shape[1]
+    out = torch.empty((B, H, W, Cc), dtype=torch.float32, device=g.device)
+    with torch.cuda.device(g.device):
+        check("frcnn_roi_crop_pool_bwd", lib.frcnn_roi_crop_pool_bwd(
+            _ptr(g), _ptr(w), _ptr(r), B, R, H, W, Cc, crop[0], crop[1], pool, _ptr(out),
+            _stream(g)))
+    return out
+
+
+def label_proposals(proposed: torch.Tensor, gt: torch.Tensor, gt_label: torch.Tensor,
+                    fg_thr: float = 0.5, iou_floor: float = 0.1, bg_label: int = 20,
+                    num_classes: int = 21, want_onehot: bool = True):
+    p = _cont(proposed, "proposed", torch.float32)
+    g = _cont(gt, "gt", torch.float32)
+    gl = _cont(gt_label, "label", torch.int64)
+    B, R = p.shape[0], p.shape[1]
+    G = g.shape[1]
+    dev = p.device
+    out = dict(
+        p_label=torch.empty((B, R), dtype=torch.int64, device=dev),
+        gt_mask=torch.empty((B, R), dtype=torch.int32, device=dev),
+        gt_onehot=torch.empty((B, R, num_classes), dtype=torch.float32, device=dev)
+        if want_onehot else None,
+        gt_coord=torch.empty((B, R, 4), dtype=torch.float32, device=dev),
+        best_gt=torch.empty((B, R), dtype=torch.int32, device=dev),
+        max_iou=torch.empty((B, R), dtype=torch.float32, device=dev),
+    )
+    with torch.cuda.device(dev):
+        check("frcnn_label_proposals", lib.frcnn_label_proposals(
+            _ptr(p), _ptr(g), _ptr(gl), B, R, G, fg_thr, iou_floor, bg_label, num_classes,
+            _ptr(out["p_label"]), _ptr(out["gt_mask"]), _ptr(out["gt_onehot"]),
+            _ptr(out["gt_coord"]), _ptr(out["best_gt"]), _ptr(out["max_iou"]), _stream(p)))
+    return out
+
+
+def sample_proposals(p_label: torch.Tensor, bg_label: int = 20, keys=None, seed: int = 0,
+                     image_base: int = 0, batch: int = 128, max_pos: int = 32):
+    """p_label [B,R] i64 -> (tindex [B,batch] i64, counts [B,4] i32)."""
+    pl = _cont(p_label, "p_label", torch.int64)
+    B, R = pl.shape
+    kp, kn, ka = _keys(keys, B, R, batch, pl.device)
+    tindex = torch.empty((B, batch), dtype=torch.int64, device=pl.device)
+    counts = torch.empty((B, 4), dtype=torch.int32, device=pl.device)
+    with torch.cuda.device(pl.device):
+        check("frcnn_sample_proposals", lib.frcnn_sample_proposals(
+            _ptr(pl), B, R, bg_label, _ptr(kp), _ptr(kn), _ptr(ka), seed & 0xFFFFFFFFFFFFFFFF,
+            image_base, batch, max_pos, _ptr(tindex), _ptr(counts), _stream(pl)))
+    return tindex, counts

@@ -1,0 +1,201 @@
+"""HIP path vs oracle on seeded inputs at the reference's own sizes
+(31x31x9 anchors, G=42, 6000 -> 1500 proposals, 14 -> 7 RoI)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import frcnn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def T(x, dev, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(x))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(dev)
+
+
+@pytest.fixture(scope="module")
+def ref_inputs():
+    d = O.synth_inputs(seed=0, B=2, H=31, W=31, A=9, C=64, G=42)
+    d["anchor"] = O.make_anchor()
+    return d
+
+
+def test_anchors_bit_exact(dev):
+    from objectdetection_amd.module import make_anchor
+    from objectdetection_amd.config import SHIP
+    a = make_anchor(device=dev).cpu().numpy()
+    assert a.shape == (31, 31, 9, 4)
+    np.testing.assert_array_equal(a, O.make_anchor())
+    s = make_anchor(SHIP, device=dev).cpu().numpy()
+    np.testing.assert_array_equal(s, O.make_anchor(32, 32, (32, 64, 128, 256), (0.5, 1, 2)))
+
+
+def test_iou_assign_bit_exact(dev, ref_inputs):
+    from objectdetection_amd import ops
+    a = ref_inputs["anchor"]
+    gt = ref_inputs["gt"]
+    mi, best, flags, full = ops.iou_assign(T(a, dev).reshape(-1, 4), T(gt, dev), want_iou=True)
+    for b in range(gt.shape[0]):
+        st = O.rpn_assign(a, gt[b])
+        np.testing.assert_array_equal(full[b].cpu().numpy(), st["iou"])
+        np.testing.assert_array_equal(best[b].cpu().numpy(), st["best"])
+        np.testing.assert_array_equal(mi[b].cpu().numpy(), st["max_iou"])
+        f = flags[b].cpu().numpy()
+        np.testing.assert_array_equal((f & 1) != 0, st["valid"])
+        np.testing.assert_array_equal(np.nonzero(f & 2)[0], st["pos_anchor"])
+
+
+@pytest.mark.parametrize("mode", ["keys", "philox"])
+def test_patch_batch_bit_exact(dev, ref_inputs, mode):
+    from objectdetection_amd.module import patch_batch
+    a = ref_inputs["anchor"]
+    N = a.shape[0] * a.shape[1] * a.shape[2]
+    rng = np.random.default_rng(5)
+    for b in range(2):
+        gt = ref_inputs["gt"][b]
+        lab = ref_inputs["label"][b]
+        if mode == "keys":
+            kp = rng.permutation(N).astype(np.uint32)
+            kn = rng.permutation(N).astype(np.uint32)
+            kt = rng.permutation(256).astype(np.uint32)
+            okeys = (kp, kn, kt)
+            dkeys = tuple(T(k.view(np.int32), dev) for k in okeys)
+        else:
+            okeys = dkeys = None
+        ref = O.patch_batch(dict(image=None, bbox=gt, label=lab), a, keys=okeys, seed=1234,
+                            image_index=b)
+        out = patch_batch(dict(image=None, bbox=T(gt, dev), label=T(lab, dev)), T(a, dev),
+                          keys=dkeys, seed=1234, image_index=b)
+        names = ["image", "batch_label", "batch_anchor", "batch_gt", "gt_list", "batch_pos",
+                 "batch_reg_gt"]
+        for i in (1, 2, 3, 4, 5):
+            np.testing.assert_array_equal(out[i].cpu().numpy(), ref[i], err_msg=names[i])
+        # encode uses log: positives within 1e-5 relative; negatives are -inf/nan by design
+        pos = ref[1][:, 0] == 1
+        np.testing.assert_allclose(out[6].cpu().numpy()[pos], ref[6][pos], rtol=1e-5, atol=1e-6)
+        np.testing.assert_array_equal(out[6].cpu().numpy()[:, :2], ref[6][:, :2])
+
+
+def test_decode_close(dev, ref_inputs):
+    from objectdetection_amd.module import inverse_trans, generate_coord
+    a = ref_inputs["anchor"]
+    got = inverse_trans(T(a, dev), T(ref_inputs["coord"], dev)).cpu().numpy()
+    ref = O.inverse_trans(a, ref_inputs["coord"])
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-7)
+    prop = ref.reshape(2, -1, 4)[:, :1500]
+    t = ref_inputs["coord"].reshape(2, -1, 4)[:, :1500]
+    got2 = generate_coord(T(prop, dev), T(t, dev)).cpu().numpy()
+    np.testing.assert_allclose(got2, O.generate_coord(prop, t), rtol=1e-5, atol=1e-7)
+
+
+def test_topk_bit_exact_with_ties(dev, ref_inputs):
+    from objectdetection_amd import ops
+    s = ref_inputs["score"].reshape(2, -1).copy()
+    s[0, 100:400] = 1.0            # saturated sigmoid ties
+    s[1, ::7] = s[1, 3]
+    s[1, 5] = -0.0
+    s[1, 6] = 0.0
+    for k in (1, 257, 6000, s.shape[1]):
+        v, i, _ = ops.topk(T(s, dev), k)
+        rv, ri = O.top_k(s, k)
+        np.testing.assert_array_equal(i.cpu().numpy(), ri)
+        np.testing.assert_array_equal(v.cpu().numpy(), rv)
+
+
+def test_proposals_bit_exact_given_boxes(dev, ref_inputs):
+    """NMS keep list on identical box inputs (device-decoded boxes fed to the oracle)."""
+    from objectdetection_amd.module.model import propose
+    a = ref_inputs["anchor"]
+    pr = propose(T(ref_inputs["score"], dev), T(ref_inputs["coord"], dev), T(a, dev))
+    cand = pr["cand"].cpu().numpy()
+    rv, ri = O.top_k(ref_inputs["score"].reshape(2, -1), 6000)
+    np.testing.assert_array_equal(pr["top_idx"].cpu().numpy(), ri)
+    ref_cand = np.take_along_axis(O.inverse_trans(a, ref_inputs["coord"]).reshape(2, -1, 4),
+                                  ri.astype(np.int64)[..., None], axis=1)
+    np.testing.assert_allclose(cand, ref_cand, rtol=1e-5, atol=1e-7)
+    proposed, keep, counts = O.combined_nms(cand, None, 1500, 0.7)
+    np.testing.assert_array_equal(pr["counts"].cpu().numpy(), counts)
+    np.testing.assert_array_equal(pr["keep_pos"].cpu().numpy(), keep)
+    np.testing.assert_array_equal(pr["proposed"].cpu().numpy(), proposed)
+
+
+def test_roi_crop_pool_exact(dev, ref_inputs):
+    from objectdetection_amd import ops
+    a = ref_inputs["anchor"]
+    pc = O.proposal_creator(ref_inputs["score"], ref_inputs["coord"], a)
+    prop = pc["proposed"][:, :300].copy()
+    prop[0, 0] = [0, 0, 1, 1]
+    prop[0, 1] = [0, 0, 0, 0]
+    prop[0, 2] = [0.25, 0.25, 0.25, 0.75]
+    fm = ref_inputs["fmap"]
+    out, win = ops.roi_crop_pool_fwd(T(fm, dev), T(prop, dev), (14, 14), 2, want_winner=True)
+    ro, ra = O.roi_crop_pool(fm, prop, (14, 14), 2)
+    np.testing.assert_array_equal(out.cpu().numpy(), ro)
+    np.testing.assert_array_equal(win.cpu().numpy(), ra)
+    crops, _ = ops.roi_crop_pool_fwd(T(fm, dev), T(prop[:, :50], dev), (14, 14), 1)
+    rc = O.crop_and_resize(fm, prop[:, :50].reshape(-1, 4), np.repeat(np.arange(2), 50))
+    np.testing.assert_array_equal(crops.cpu().numpy().reshape(rc.shape), rc)
+    # NCHW-contiguous storage viewed as NHWC goes through the any-stride kernel
+    f_nchw = T(fm, dev).permute(0, 3, 1, 2).contiguous().permute(0, 2, 3, 1)
+    out2, _ = ops.roi_crop_pool_fwd(f_nchw, T(prop[:, :50], dev), (14, 14), 2)
+    np.testing.assert_array_equal(out2.cpu().numpy(), ro[:, :50])
+
+
+def test_roi_backward_exact(dev):
+    from objectdetection_amd import ops
+    d = O.synth_inputs(seed=3, B=1, H=9, W=11, A=1, C=8, G=4)
+    rng = np.random.default_rng(0)
+    R = 12
+    y1 = rng.uniform(0, 0.6, R); x1 = rng.uniform(0, 0.6, R)
+    prop = np.stack([y1, x1, y1 + rng.uniform(0.05, 0.4, R), x1 + rng.uniform(0.05, 0.4, R)],
+                    1).astype(np.float32)[None]
+    prop[0, 0] = [0, 0, 1, 1]
+    prop[0, 1] = [0, 0, 0, 0]
+    fm = d["fmap"]
+    out, win = ops.roi_crop_pool_fwd(T(fm, dev), T(prop, dev), (14, 14), 2, want_winner=True)
+    dY = rng.standard_normal(out.shape).astype(np.float32)
+    got = ops.roi_crop_pool_bwd(T(dY, dev), win, T(prop, dev), fm.shape, (14, 14), 2)
+    ref = O.roi_crop_pool_bwd(dY, win.cpu().numpy(), fm.shape, prop, (14, 14), 2)
+    np.testing.assert_array_equal(got.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("mode", ["keys", "philox"])
+def test_making_frcnn_input(dev, ref_inputs, mode):
+    from objectdetection_amd import ops
+    from objectdetection_amd.module import making_frcnn_input
+    a = ref_inputs["anchor"]
+    d = ref_inputs
+    rng = np.random.default_rng(9)
+    if mode == "keys":
+        ok = [(rng.permutation(1500).astype(np.uint32), rng.permutation(1500).astype(np.uint32),
+               rng.permutation(128).astype(np.uint32)) for _ in range(2)]
+        dk = tuple(T(np.stack([k[j] for k in ok]).view(np.int32), dev) for j in range(3))
+    else:
+        ok = dk = None
+    crop, gl, gm, gc, proposed, tindex = making_frcnn_input(
+        T(d["gt"], dev), T(d["label"], dev), T(d["fmap"], dev), T(d["coord"], dev),
+        T(d["score"], dev), T(a, dev), keys=dk, seed=77)
+    # oracle labelling on the device's proposals (identical inputs)
+    prop = proposed.cpu().numpy()
+    lab = O.label_proposals(prop, d["gt"], d["label"])
+    dl = ops.label_proposals(proposed, T(d["gt"], dev), T(d["label"], dev))
+    np.testing.assert_array_equal(dl["p_label"].cpu().numpy(), lab["p_iou"])
+    np.testing.assert_array_equal(dl["gt_mask"].cpu().numpy(), lab["gt_mask"])
+    np.testing.assert_array_equal(dl["best_gt"].cpu().numpy(), lab["best"])
+    np.testing.assert_array_equal(dl["max_iou"].cpu().numpy(), lab["max_iou"])
+    np.testing.assert_array_equal(dl["gt_onehot"].cpu().numpy(), lab["gt_label"])
+    ti = O.sample_proposals(lab["p_iou"], keys=ok, seed=77)
+    np.testing.assert_array_equal(tindex.cpu().numpy(), ti)
+    np.testing.assert_array_equal(gm.cpu().numpy(), np.take_along_axis(lab["gt_mask"], ti, 1))
+    np.testing.assert_array_equal(gl.cpu().numpy(),
+                                  np.take_along_axis(lab["gt_label"], ti[..., None], 1))
+    ref_gc = np.take_along_axis(lab["gt_coord"], ti[..., None], 1)
+    fin = np.isfinite(ref_gc)
+    np.testing.assert_array_equal(np.isfinite(gc.cpu().numpy()), fin)
+    np.testing.assert_allclose(gc.cpu().numpy()[fin], ref_gc[fin], rtol=1e-5, atol=1e-6)
+    rc = O.crop_and_resize(d["fmap"], prop[:, :40].reshape(-1, 4), np.repeat(np.arange(2), 40))
+    np.testing.assert_array_equal(crop[:, :40].cpu().numpy().reshape(rc.shape), rc)
