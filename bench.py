@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the fused RPN path (anchor match +
+proposal NMS + RoI crop/pool) on synthetic 600x1000 images.
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: under torch.distributed.run)
+
+One step = one pass of the whole hot path (RegionProposalPath.run, training
+mode) over `--batch` images per GPU whose inputs are already resident in HBM.
+Images are independent units: rank r works on its own batch, no data-path
+collective; the barrier and the max-over-ranks time are the only communication.
+Rank 0 prints one JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak
+
+
+def workload_cfg():
+    from objectdetection_amd.config import PathConfig
+    # 600x1000 image, VGG16 stride 16 -> 37x62 map, 9 anchors (20,646), G=42,
+    # 12k -> 2k NMS at 0.7, RoI 14 -> 7, C=512.
+    return PathConfig(H=37, W=62, scales=(128, 256, 512), ratios=(0.5, 1, 2), base_w=1000.0,
+                      base_h=600.0, G=42, pre_k=12000, post_n=2000, nms_thr=0.7)
+
+
+def make_inputs(cfg, B, C, device, seed):
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    score = torch.sigmoid(torch.randn((B, cfg.H, cfg.W, cfg.A), generator=g, device=device) * 2.0)
+    coord = torch.randn((B, cfg.H, cfg.W, 4 * cfg.A), generator=g, device=device) * 0.5
+    fmap = torch.relu(torch.randn((B, cfg.H, cfg.W, C), generator=g, device=device))
+    rng = np.random.Generator(np.random.PCG64(seed))
+    gt = np.zeros((B, cfg.G, 4), np.float32)
+    label = np.zeros((B, cfg.G), np.int64)
+    for b in range(B):
+        n = int(rng.integers(1, cfg.G + 1))
+        cy, cx = rng.uniform(0.05, 0.95, n), rng.uniform(0.05, 0.95, n)
+        hh = np.exp(rng.uniform(np.log(0.05), np.log(0.6), n))
+        ww = np.exp(rng.uniform(np.log(0.05), np.log(0.6), n))
+        gt[b, :n] = np.clip(np.stack([cy - hh / 2, cx - ww / 2, cy + hh / 2, cx + ww / 2], 1), 0, 1)
+        label[b, :n] = rng.integers(0, 20, n)
+    return (fmap.contiguous(), score.contiguous(), coord.contiguous(),
+            torch.from_numpy(gt).to(device), torch.from_numpy(label).to(device))
+
+
+def algorithmic_bytes_roi(cfg, C, B):
+    """RoI kernel, per launch: feature map read once + pooled tensor written once."""
+    ph, pw = cfg.crop[0] // cfg.pool, cfg.crop[1] // cfg.pool
+    per_image = cfg.H * cfg.W * C * 4 + cfg.post_n * ph * pw * C * 4 + cfg.post_n * 16
+    return per_image * B
+
+
+def cpu_baseline(cfg, fmap, score, coord, gt, label):
+    """numpy restatement (oracle) of the same step on ONE image, one thread."""
+    from oracle import frcnn_oracle as O
+    a = O.make_anchor(cfg.H, cfg.W, cfg.scales, cfg.ratios, cfg.base_w, cfg.base_h)
+    f, s, c = fmap[:1].cpu().numpy(), score[:1].cpu().numpy(), coord[:1].cpu().numpy()
+    g, l = gt[:1].cpu().numpy(), label[:1].cpu().numpy()
+    t0 = time.perf_counter()
+    O.patch_batch(dict(image=None, bbox=g[0], label=l[0]), a, seed=0, batch=cfg.rpn_batch,
+                  max_pos=cfg.rpn_max_pos)
+    pc = O.proposal_creator(s, c, a, cfg.pre_k, cfg.post_n, cfg.nms_thr)
+    O.roi_crop_pool(f, pc["proposed"], cfg.crop, cfg.pool)
+    lab = O.label_proposals(pc["proposed"], g, l, cfg.fg_thr, cfg.iou_floor, cfg.bg_label,
+                            cfg.num_classes)
+    O.sample_proposals(lab["p_iou"], seed=0, batch=cfg.head_batch, max_pos=cfg.head_max_pos,
+                       bg_label=cfg.bg_label)
+    dt = time.perf_counter() - t0
+    return dict(value=1.0 / dt, unit="images/s", cores=1, kind="port",
+                sample=f"1 image of the same workload, numpy oracle, {dt:.2f} s, "
+                       f"host has {os.cpu_count()} logical CPUs")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
+    ap.add_argument("--channels", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inference", action="store_true", help="skip the training-only stages")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    from objectdetection_amd.pipeline import RegionProposalPath
+    cfg = workload_cfg()
+    B, C = args.batch, args.channels
+    fmap, score, coord, gt, label = make_inputs(cfg, B, C, device, seed=1000 + rank)
+    path = RegionProposalPath(cfg, B, C, device, train=not args.inference)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    for w in range(args.warmup):
+        path.run(fmap, score, coord, gt, label, seed=w, image_base=rank * B)
+    sync()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        path.run(fmap, score, coord, gt, label, seed=100 + k, image_base=rank * B,
+                 roi_events=ev[k])
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        roi_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        alg = algorithmic_bytes_roi(cfg, C, B)
+        achieved = alg / (roi_ms * 1e-3) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "roi_fwd_traffic.json")
+        if os.path.exists(tf):
+            with open(tf) as fh:
+                rec = json.load(fh)
+            if rec.get("batch") == B and rec.get("channels") == C:
+                traffic = rec.get("hbm_bytes_per_launch")
+        kept = path.keep_count.float().mean().item()
+        out = {
+            "metric": "images/sec (RPN anchor-match+proposal NMS+RoIPool) 600x1000",
+            "value": world * B * args.steps / elapsed,
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "600x1000 image -> 37x62x9 = 20,646 anchors, G=42, top-12000 -> "
+                            "NMS 0.7 -> 2000, RoI crop 14 -> pool 7, C=512; "
+                            + ("inference stages only" if args.inference else
+                               "with RPN + head target sampling (training forward)"),
+                "images_per_gpu_per_step": B,
+                "mean_kept_proposals": kept,
+            },
+            "roofline": {
+                "kernel": "roi_fwd_cl_kernel<2>",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "avg_launch_ms": roi_ms,
+                "algorithmic_bytes_per_launch": alg,
+            },
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, fmap, score, coord, gt, label)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -128,9 +128,8 @@ extern "C" int frcnn_anchors(float* anchors, int H, int W, const double* scales,
             half.hh[s * n_ratios + r] = h / 2.0;
         }
     const int total = H * W * A;
-    hipLaunchKernelGGL(anchors_kernel, dim3((total + 255) / 256), dim3(256), 0,
+    FRCNN_LAUNCH(anchors_kernel, dim3((total + 255) / 256), dim3(256), 0,
                        (hipStream_t)stream, reinterpret_cast<float4*>(anchors), H, W, A, half);
-    FRCNN_LAUNCH_CHECK();
     return FRCNN_OK;
 }
 
@@ -141,11 +140,10 @@ extern "C" int frcnn_iou_assign(const float* anchors, int N, const float* gt, in
         return FRCNN_E_BADARG;
     if (G > 2048 || B > 65535) return FRCNN_E_UNSUPPORTED;
     const size_t lds = (size_t)G * 20;
-    hipLaunchKernelGGL(iou_assign_kernel, dim3((N + 255) / 256, B), dim3(256), lds,
+    FRCNN_LAUNCH(iou_assign_kernel, dim3((N + 255) / 256, B), dim3(256), lds,
                        (hipStream_t)stream, reinterpret_cast<const float4*>(anchors), N,
                        reinterpret_cast<const float4*>(gt), G, pos_thr, neg_thr, max_iou, best_gt,
                        flags, iou_full);
-    FRCNN_LAUNCH_CHECK();
     return FRCNN_OK;
 }
 
@@ -156,11 +154,10 @@ extern "C" int frcnn_decode_clip(const float* anchors, const float* deltas, int 
     const long long total = (long long)B * n_anchor;
     const long long blocks = (total + 255) / 256;
     if (blocks > 0x7FFFFFFFll) return FRCNN_E_UNSUPPORTED;
-    hipLaunchKernelGGL(decode_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+    FRCNN_LAUNCH(decode_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const float4*>(anchors),
                        reinterpret_cast<const float4*>(deltas), (long long)n_anchor, total, clip_wh,
                        reinterpret_cast<float4*>(boxes));
-    FRCNN_LAUNCH_CHECK();
     return FRCNN_OK;
 }
 
@@ -169,9 +166,8 @@ extern "C" int frcnn_encode(const float* anchor, const float* gt, int64_t n, int
     if (!anchor || !gt || !target || n <= 0) return FRCNN_E_BADARG;
     const long long blocks = ((long long)n + 255) / 256;
     if (blocks > 0x7FFFFFFFll) return FRCNN_E_UNSUPPORTED;
-    hipLaunchKernelGGL(encode_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+    FRCNN_LAUNCH(encode_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const float4*>(anchor), reinterpret_cast<const float4*>(gt),
                        (long long)n, clip_wh, reinterpret_cast<float4*>(target));
-    FRCNN_LAUNCH_CHECK();
     return FRCNN_OK;
 }

@@ -9,9 +9,13 @@
 
 #define FRCNN_WAVE 64
 
-#define FRCNN_LAUNCH_CHECK()                                   \
-    do {                                                       \
-        if (hipGetLastError() != hipSuccess) return FRCNN_E_LAUNCH; \
+// hipGetLastError() also reports errors left behind by earlier, unrelated
+// runtime calls of this thread: clear it before a launch, read it after.
+#define FRCNN_LAUNCH(kernel, grid, block, lds, stream, ...)                         \
+    do {                                                                            \
+        (void)hipGetLastError();                                                    \
+        hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);          \
+        if (hipGetLastError() != hipSuccess) return FRCNN_E_LAUNCH;                 \
     } while (0)
 
 namespace frcnn {

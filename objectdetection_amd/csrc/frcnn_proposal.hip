@@ -212,11 +212,10 @@ extern "C" int frcnn_topk(const float* scores, int B, int N, int K, const float*
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(topk_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return FRCNN_E_LAUNCH;
-    hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(TBLOCK), lds, (hipStream_t)stream, scores, N, K,
+    FRCNN_LAUNCH(topk_kernel, dim3(B), dim3(TBLOCK), lds, (hipStream_t)stream, scores, N, K,
                        n_pad, reinterpret_cast<const float4*>(anchors),
                        reinterpret_cast<const float4*>(deltas), top_scores, top_idx,
                        fuse ? reinterpret_cast<float4*>(cand_boxes) : nullptr);
-    FRCNN_LAUNCH_CHECK();
     return FRCNN_OK;
 }
 
@@ -240,18 +239,16 @@ extern "C" int frcnn_nms(const float* boxes, int B, int K, float iou_threshold, 
     // band edges for the division-free fast path of iou_over()
     const float thr_lo = iou_threshold * 0.999998f;
     const float thr_hi = iou_threshold * 1.000002f;
-    hipLaunchKernelGGL(nms_mask_kernel, dim3((CB + 3) / 4, CB, B), dim3(256), 0,
+    FRCNN_LAUNCH(nms_mask_kernel, dim3((CB + 3) / 4, CB, B), dim3(256), 0,
                        (hipStream_t)stream, reinterpret_cast<const float4*>(boxes), K, CB,
                        iou_threshold, thr_lo, thr_hi, mask);
-    FRCNN_LAUNCH_CHECK();
     const size_t lds = (size_t)CB * 8;
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(nms_scan_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return FRCNN_E_LAUNCH;
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(64), lds, (hipStream_t)stream,
+    FRCNN_LAUNCH(nms_scan_kernel, dim3(B), dim3(64), lds, (hipStream_t)stream,
                        reinterpret_cast<const float4*>(boxes), mask, K, CB, post_n,
                        reinterpret_cast<float4*>(proposed), keep_pos, keep_count);
-    FRCNN_LAUNCH_CHECK();
     return FRCNN_OK;
 }

@@ -278,24 +278,23 @@ extern "C" int frcnn_roi_crop_pool_fwd(const float* fmap, int B, int H, int W, i
     hipStream_t st = (hipStream_t)stream;
     if (fast) {
         if (pool == 2)
-            hipLaunchKernelGGL(roi_fwd_cl_kernel<2>, grid, block, 0, st, fmap, H, W, C,
+            FRCNN_LAUNCH(roi_fwd_cl_kernel<2>, grid, block, 0, st, fmap, H, W, C,
                                (long long)sb, (long long)sh, (long long)sw, rb, R, crop_h, crop_w,
                                out, winner);
         else
-            hipLaunchKernelGGL(roi_fwd_cl_kernel<1>, grid, block, 0, st, fmap, H, W, C,
+            FRCNN_LAUNCH(roi_fwd_cl_kernel<1>, grid, block, 0, st, fmap, H, W, C,
                                (long long)sb, (long long)sh, (long long)sw, rb, R, crop_h, crop_w,
                                out, winner);
     } else {
         if (pool == 2)
-            hipLaunchKernelGGL(roi_fwd_generic_kernel<2>, grid, block, 0, st, fmap, H, W, C,
+            FRCNN_LAUNCH(roi_fwd_generic_kernel<2>, grid, block, 0, st, fmap, H, W, C,
                                (long long)sb, (long long)sh, (long long)sw, (long long)sc, rb, R,
                                crop_h, crop_w, out, winner);
         else
-            hipLaunchKernelGGL(roi_fwd_generic_kernel<1>, grid, block, 0, st, fmap, H, W, C,
+            FRCNN_LAUNCH(roi_fwd_generic_kernel<1>, grid, block, 0, st, fmap, H, W, C,
                                (long long)sb, (long long)sh, (long long)sw, (long long)sc, rb, R,
                                crop_h, crop_w, out, winner);
     }
-    FRCNN_LAUNCH_CHECK();
     return FRCNN_OK;
 }
 
@@ -317,11 +316,10 @@ extern "C" int frcnn_roi_crop_pool_bwd(const float* dY, const uint8_t* winner, c
     const float4* rb = reinterpret_cast<const float4*>(rois);
     hipStream_t st = (hipStream_t)stream;
     if (pool == 2)
-        hipLaunchKernelGGL(roi_bwd_cl_kernel<2>, grid, block, 0, st, dY, winner, rb, R, H, W, C,
+        FRCNN_LAUNCH(roi_bwd_cl_kernel<2>, grid, block, 0, st, dY, winner, rb, R, H, W, C,
                            crop_h, crop_w, dfmap);
     else
-        hipLaunchKernelGGL(roi_bwd_cl_kernel<1>, grid, block, 0, st, dY, winner, rb, R, H, W, C,
+        FRCNN_LAUNCH(roi_bwd_cl_kernel<1>, grid, block, 0, st, dY, winner, rb, R, H, W, C,
                            crop_h, crop_w, dfmap);
-    FRCNN_LAUNCH_CHECK();
     return FRCNN_OK;
 }

@@ -332,14 +332,13 @@ extern "C" int frcnn_rpn_sample(const float* anchors, int H, int W, int A, const
     if (any && !all) return FRCNN_E_BADARG;
     const long long N = (long long)H * W * A;
     if (N > (1ll << 24) || batch > SMAX_BATCH) return FRCNN_E_UNSUPPORTED;
-    hipLaunchKernelGGL(rpn_sample_kernel, dim3(B), dim3(SBLOCK), 0, (hipStream_t)stream,
+    FRCNN_LAUNCH(rpn_sample_kernel, dim3(B), dim3(SBLOCK), 0, (hipStream_t)stream,
                        reinterpret_cast<const float4*>(anchors), (int)N, W, A,
                        reinterpret_cast<const float4*>(gt), G, best_gt, flags, keys_pos, keys_neg,
                        keys_all, seed, image_base, batch, max_pos, batch_label,
                        reinterpret_cast<float4*>(batch_anchor), reinterpret_cast<float4*>(batch_gt),
                        reinterpret_cast<long long*>(gt_list), reinterpret_cast<long long*>(batch_pos),
                        reinterpret_cast<float4*>(batch_reg_gt), counts);
-    FRCNN_LAUNCH_CHECK();
     return FRCNN_OK;
 }
 
@@ -355,11 +354,10 @@ extern "C" int frcnn_sample_proposals(const int64_t* p_label, int B, int R, int 
     const bool all = keys_pos && keys_neg && keys_all;
     if (any && !all) return FRCNN_E_BADARG;
     if (R > (1 << 24) || batch > SMAX_BATCH) return FRCNN_E_UNSUPPORTED;
-    hipLaunchKernelGGL(sample_proposals_kernel, dim3(B), dim3(SBLOCK), 0, (hipStream_t)stream,
+    FRCNN_LAUNCH(sample_proposals_kernel, dim3(B), dim3(SBLOCK), 0, (hipStream_t)stream,
                        reinterpret_cast<const long long*>(p_label), R, bg_label, keys_pos, keys_neg,
                        keys_all, seed, image_base, batch, max_pos,
                        reinterpret_cast<long long*>(tindex), counts);
-    FRCNN_LAUNCH_CHECK();
     return FRCNN_OK;
 }
 
@@ -374,12 +372,11 @@ extern "C" int frcnn_label_proposals(const float* proposed, const float* gt,
         return FRCNN_E_BADARG;
     if (G > 2048 || B > 65535) return FRCNN_E_UNSUPPORTED;
     const size_t lds = (size_t)G * (16 + 8 + 4);
-    hipLaunchKernelGGL(label_proposals_kernel, dim3((R + 255) / 256, B), dim3(256), lds,
+    FRCNN_LAUNCH(label_proposals_kernel, dim3((R + 255) / 256, B), dim3(256), lds,
                        (hipStream_t)stream, reinterpret_cast<const float4*>(proposed),
                        reinterpret_cast<const float4*>(gt),
                        reinterpret_cast<const long long*>(gt_label_in), R, G, fg_thr, iou_floor,
                        bg_label, num_classes, reinterpret_cast<long long*>(p_label), gt_mask,
                        gt_onehot, reinterpret_cast<float4*>(gt_coord), best_gt, max_iou);
-    FRCNN_LAUNCH_CHECK();
     return FRCNN_OK;
 }
