@@ -29,7 +29,7 @@ __device__ __forceinline__ void axis_sample(float c1, float c2, int dim, int n, 
     } else {
         in = (float)(0.5 * (double)(c1 + c2) * (double)(dim - 1));
     }
-    ok = !(in < 0.0f || in > (float)(dim - 1));
+    ok = (in >= 0.0f && in <= (float)(dim - 1));      // NaN -> extrapolated
     const float f = floorf(in), c = ceilf(in);
     frac = in - f;
     lo = ok ? (int)f : 0;
@@ -110,6 +110,213 @@ roi_fwd_cl_kernel(const float* __restrict__ fmap, int H, int W, int C, long long
             }
         }
     }
+}
+
+// ---- channels-last "row walker" (C % 64 == 0, crop <= 16x16).
+// Workgroup = one RoI x one 64-channel slice (slice = blockIdx.x % nslice: with
+// 8 slices the blocks dispatched together cover one RoI and each XCD keeps
+// seeing the same eighth of the feature map); thread = (channel quad, pooled
+// column q); no LDS, no barrier: every wave is self-contained.
+//
+// The sample rows of a box touch an ascending list of distinct feature rows.
+// Each thread walks that list once: per feature row it loads the four cells
+// its POOL sample columns need (the next row already in flight), lerps them
+// horizontally, and keeps the last two lerped rows in registers; every sample
+// row whose bottom row has arrived is then finished with one vertical lerp per
+// sample column and folded into the running max of its pool window.  A
+// feature row shared by several sample rows (small boxes) is fetched once.
+//
+// The row list and the per-sample-row (top, bottom, weight) live one entry per
+// lane and are read with v_readlane by the uniform loop counters, so the loop
+// control runs on the scalar unit.
+constexpr int RW_CS = 64;
+constexpr int RW_LANES = RW_CS / 4;
+constexpr int RW_MAXCROP = 16;
+
+struct RowWalk {
+    int t_lo, t_hi;     // lane s: unique-row index of sample row s (top, bottom); -1 extrapolated
+    float t_fr;         // lane s: vertical lerp weight of sample row s
+    int t_row;          // lane j: feature row of unique-row j
+    int nr;             // number of unique rows (uniform)
+    bool walk;          // false: flipped box, t_lo/t_hi hold raw rows
+};
+
+// Every wave builds the table for itself.  Lane 2s / 2s+1 = floor / ceil row of
+// sample s; in an ascending sequence a value can only repeat one of the
+// previous two entries, so two shuffles find the first occurrences.
+__device__ __forceinline__ RowWalk build_row_walk(float y1, float y2, int H, int ch) {
+    const int lane = lane_id();
+    const int s = lane >> 1, which = lane & 1;
+    int lo = 0, hi = 0, ok = 0;
+    float fr = 0.f;
+    if (s < ch) axis_sample(y1, y2, H, ch, s, lo, hi, fr, ok);
+    const bool valid = s < ch && ok;
+    RowWalk w;
+    w.walk = !(y2 < y1);
+    const int v = valid ? (which ? hi : lo) : -1 - lane;
+    const int v1 = __shfl_up(v, 1), v2 = __shfl_up(v, 2);
+    const bool is_first = valid && (lane < 1 || v != v1) && (lane < 2 || v != v2);
+    const unsigned long long fm = __ballot(is_first);
+    const unsigned long long le = fm & (lanemask_lt() | (1ull << lane));
+    const int cnt = __popcll(le);
+    const int F = le ? 63 - __clzll((long long)le) : 0;
+    const int vF = __shfl(v, F);
+    int idx = (v == vF) ? cnt - 1 : cnt - 2;
+    if (!w.walk) idx = v;
+    const int src = (2 * lane) & 63;
+    const int s_ok = __shfl((int)valid, src);
+    w.t_lo = __shfl(idx, src);
+    w.t_hi = __shfl(idx, src | 1);
+    w.t_fr = __shfl(fr, src);
+    if (!(lane < ch && s_ok)) { w.t_lo = -1; w.t_hi = -1; }
+    // scatter: unique-row slot (cnt-1) <- v; lanes that are not a first occurrence aim at lane 63
+    w.t_row = __builtin_amdgcn_ds_permute((is_first ? cnt - 1 : 63) << 2, v);
+    w.nr = __popcll(fm);
+    return w;
+}
+
+__device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ float rlf(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+template <int POOL, bool WIN>
+__global__ void __launch_bounds__(256)
+roi_fwd_walk_kernel(const float* __restrict__ fmap, int H, int W, int C, long long sb, long long sh,
+                    long long sw, const float4* __restrict__ rois, int R, int ch, int cw,
+                    int nslice, float* __restrict__ out, uint8_t* __restrict__ winner) {
+    const int tid = threadIdx.x;
+    const int slice = blockIdx.x % nslice, r = blockIdx.x / nslice, b = blockIdx.y;
+    const float4 box = rois[(size_t)b * R + r];
+    const RowWalk rw = build_row_walk(box.x, box.z, H, ch);
+    const int ph = ch / POOL, pw = cw / POOL;
+    const int cq = tid & (RW_LANES - 1), q = tid / RW_LANES;
+    // this thread's sample columns: byte offsets inside a feature row (32-bit)
+    uint32_t xlo[POOL], xhi[POOL];
+    float xfr[POOL];
+    bool xok[POOL];
+    const uint32_t chan_off = (uint32_t)(slice * RW_CS + cq * 4) * 4u;
+#pragma unroll
+    for (int k = 0; k < POOL; ++k) {
+        int lo = 0, hi = 0, ok = 0;
+        float fr = 0.f;
+        const int sx = q * POOL + k;
+        if (sx < cw) axis_sample(box.y, box.w, W, cw, sx, lo, hi, fr, ok);
+        xlo[k] = (uint32_t)lo * (uint32_t)sw * 4u + chan_off;
+        xhi[k] = (uint32_t)hi * (uint32_t)sw * 4u + chan_off;
+        xfr[k] = fr;
+        xok[k] = sx < cw && ok;
+    }
+    if (q >= pw) return;
+    const char* img = reinterpret_cast<const char*>(fmap) + (size_t)b * sb * 4;        // uniform
+    const size_t oroi = ((size_t)b * R + r) * (size_t)(ph * pw) * C;                    // uniform
+    const uint32_t ooff = (uint32_t)q * (uint32_t)C * 4u + chan_off;                   // per thread
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int nsy = ph * POOL;
+    float4 best = zero;
+    uchar4 arg = make_uchar4(0, 0, 0, 0);
+
+    auto fold = [&](int sy, const float4 (&v)[POOL]) {
+        const int ky = sy % POOL;
+#pragma unroll
+        for (int kx = 0; kx < POOL; ++kx) {
+            const int k = ky * POOL + kx;
+            if (k == 0) {
+                best = v[kx];
+                if (WIN) arg = make_uchar4(0, 0, 0, 0);
+            } else if (WIN) {
+                if (v[kx].x > best.x) { best.x = v[kx].x; arg.x = k; }
+                if (v[kx].y > best.y) { best.y = v[kx].y; arg.y = k; }
+                if (v[kx].z > best.z) { best.z = v[kx].z; arg.z = k; }
+                if (v[kx].w > best.w) { best.w = v[kx].w; arg.w = k; }
+            } else {
+                best.x = fmaxf(best.x, v[kx].x); best.y = fmaxf(best.y, v[kx].y);
+                best.z = fmaxf(best.z, v[kx].z); best.w = fmaxf(best.w, v[kx].w);
+            }
+        }
+        if (ky == POOL - 1) {
+            const size_t orow = (oroi + (size_t)(sy / POOL) * pw * C) * 4;             // uniform
+            *reinterpret_cast<float4*>(reinterpret_cast<char*>(out) + orow + ooff) = best;
+            if (WIN)
+                *reinterpret_cast<uchar4*>(winner + (orow >> 2) + (ooff >> 2)) = arg;
+        }
+    };
+
+    if (!rw.walk) {
+        // flipped box: rows are not ascending; fetch every corner directly
+        for (int sy = 0; sy < nsy; ++sy) {
+            const int lo = rl(rw.t_lo, sy), hi = rl(rw.t_hi, sy);
+            const float fr = rlf(rw.t_fr, sy);
+            float4 v[POOL];
+#pragma unroll
+            for (int k = 0; k < POOL; ++k) {
+                v[k] = zero;
+                if (lo >= 0 && xok[k]) {
+                    const char* rt = img + (size_t)lo * sh * 4;
+                    const char* rb = img + (size_t)hi * sh * 4;
+                    const float4 top = lerp4(*reinterpret_cast<const float4*>(rt + xlo[k]),
+                                             *reinterpret_cast<const float4*>(rt + xhi[k]), xfr[k]);
+                    const float4 bot = lerp4(*reinterpret_cast<const float4*>(rb + xlo[k]),
+                                             *reinterpret_cast<const float4*>(rb + xhi[k]), xfr[k]);
+                    v[k] = lerp4(top, bot, fr);
+                }
+            }
+            fold(sy, v);
+        }
+        return;
+    }
+
+    const int NR = rw.nr;
+    float4 hA[POOL], hB[POOL], lAl[POOL], lAr[POOL], lBl[POOL], lBr[POOL];
+#pragma unroll
+    for (int k = 0; k < POOL; ++k) { hA[k] = hB[k] = lAl[k] = lAr[k] = lBl[k] = lBr[k] = zero; }
+    int sy = 0;
+
+    auto load_row = [&](int j, float4 (&ll)[POOL], float4 (&lr)[POOL]) {
+        const char* row = img + (size_t)rl(rw.t_row, j) * sh * 4;                       // uniform
+#pragma unroll
+        for (int k = 0; k < POOL; ++k) {
+            ll[k] = *reinterpret_cast<const float4*>(row + xlo[k]);
+            lr[k] = *reinterpret_cast<const float4*>(row + xhi[k]);
+        }
+    };
+    // finish every sample row that needs nothing beyond unique row j
+    auto drain = [&](int j, const float4 (&hc)[POOL], const float4 (&hp)[POOL]) {
+        while (sy < nsy) {
+            const int lo = rl(rw.t_lo, sy), hi = rl(rw.t_hi, sy);
+            if (lo >= 0 && hi > j) break;
+            const float fr = rlf(rw.t_fr, sy);
+            float4 v[POOL];
+            if (lo < 0) {
+#pragma unroll
+                for (int k = 0; k < POOL; ++k) v[k] = zero;
+            } else if (lo == j) {
+#pragma unroll
+                for (int k = 0; k < POOL; ++k) v[k] = xok[k] ? lerp4(hc[k], hc[k], fr) : zero;
+            } else {
+#pragma unroll
+                for (int k = 0; k < POOL; ++k) v[k] = xok[k] ? lerp4(hp[k], hc[k], fr) : zero;
+            }
+            fold(sy, v);
+            ++sy;
+        }
+    };
+    auto step = [&](int j, float4 (&hc)[POOL], const float4 (&hp)[POOL], const float4 (&cl)[POOL],
+                    const float4 (&cr)[POOL], float4 (&nl)[POOL], float4 (&nr_)[POOL]) {
+        load_row(min(j + 1, NR - 1), nl, nr_);          // next row in flight (last row: reloaded)
+#pragma unroll
+        for (int k = 0; k < POOL; ++k) hc[k] = lerp4(cl[k], cr[k], xfr[k]);
+        drain(j, hc, hp);
+    };
+
+    drain(-1, hA, hB);                                   // leading extrapolated sample rows
+    if (NR > 0) load_row(0, lAl, lAr);
+#pragma unroll 1
+    for (int j = 0; j < NR; j += 2) {
+        step(j, hA, hB, lAl, lAr, lBl, lBr);
+        if (j + 1 < NR) step(j + 1, hB, hA, lBl, lBr, lAl, lAr);
+    }
+    drain(NR, hA, hB);                                   // trailing extrapolated sample rows
 }
 
 // ---- any-stride fallback: one thread per channel.
@@ -276,7 +483,21 @@ extern "C" int frcnn_roi_crop_pool_fwd(const float* fmap, int B, int H, int W, i
     const dim3 grid(R, B), block(128);
     const float4* rb = reinterpret_cast<const float4*>(rois);
     hipStream_t st = (hipStream_t)stream;
-    if (fast) {
+    const bool walk_path = fast && (C % RW_CS) == 0 && crop_h <= RW_MAXCROP &&
+                           crop_w <= RW_MAXCROP && (long long)R * (C / RW_CS) <= 0x7FFFFFFFll &&
+                           (long long)W * sw * 4 + (long long)C * 4 < 0x7FFFFFFFll &&
+                           (long long)(crop_w / pool) * C * 4 < 0x7FFFFFFFll;
+    if (walk_path) {
+        const int nslice = C / RW_CS;
+        const int pw = crop_w / pool;
+        const dim3 g3((unsigned)(R * nslice), B), b3(64 * ((pw + 3) / 4));
+#define FRCNN_WALK(P, WN)                                                                       \
+    FRCNN_LAUNCH((roi_fwd_walk_kernel<P, WN>), g3, b3, 0, st, fmap, H, W, C, (long long)sb,     \
+                 (long long)sh, (long long)sw, rb, R, crop_h, crop_w, nslice, out, winner)
+        if (pool == 2) { if (winner) FRCNN_WALK(2, true); else FRCNN_WALK(2, false); }
+        else           { FRCNN_WALK(1, false); }
+#undef FRCNN_WALK
+    } else if (fast) {
         if (pool == 2)
             FRCNN_LAUNCH(roi_fwd_cl_kernel<2>, grid, block, 0, st, fmap, H, W, C,
                                (long long)sb, (long long)sh, (long long)sw, rb, R, crop_h, crop_w,

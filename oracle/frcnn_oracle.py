@@ -413,8 +413,8 @@ def _crop_geometry(boxes, H, W, ch, cw):
     else:
         in_x = (0.5 * (x1 + x2).astype(np.float64) * np.float64(W - 1)).astype(F32)[:, None]
     in_y = in_y.astype(F32); in_x = in_x.astype(F32)
-    y_ok = ~((in_y < 0) | (in_y > F32(H - 1)))
-    x_ok = ~((in_x < 0) | (in_x > F32(W - 1)))
+    y_ok = (in_y >= 0) & (in_y <= F32(H - 1))      # NaN -> extrapolated (build-defined)
+    x_ok = (in_x >= 0) & (in_x <= F32(W - 1))
     top = np.floor(in_y); bot = np.ceil(in_y)
     left = np.floor(in_x); right = np.ceil(in_x)
     ly = (in_y - top).astype(F32); lx = (in_x - left).astype(F32)

@@ -123,7 +123,10 @@ def test_proposals_bit_exact_given_boxes(dev, ref_inputs):
     np.testing.assert_array_equal(pr["proposed"].cpu().numpy(), proposed)
 
 
-def test_roi_crop_pool_exact(dev, ref_inputs):
+@pytest.mark.parametrize("C", [64, 32, 192, 6])
+def test_roi_crop_pool_exact(dev, ref_inputs, C):
+    """C=64/192: LDS-staged kernel (1 and 3 channel slices); C=32: direct
+    channels-last kernel; C=6: any-stride kernel."""
     from objectdetection_amd import ops
     a = ref_inputs["anchor"]
     pc = O.proposal_creator(ref_inputs["score"], ref_inputs["coord"], a)
@@ -131,7 +134,11 @@ def test_roi_crop_pool_exact(dev, ref_inputs):
     prop[0, 0] = [0, 0, 1, 1]
     prop[0, 1] = [0, 0, 0, 0]
     prop[0, 2] = [0.25, 0.25, 0.25, 0.75]
-    fm = ref_inputs["fmap"]
+    prop[0, 3] = [0.5, 0.5, 1.0, 1.0]          # edge samples land exactly on H-1 / W-1
+    prop[0, 4] = [0.9, 0.1, 0.2, 0.8]          # flipped box (y2 < y1)
+    prop[0, 5] = [0.0, 0.0, 1.0 + 1e-6, 1.0]   # last row falls outside -> zeros
+    fm = np.tile(ref_inputs["fmap"], (1, 1, 1, 3))[..., :C]
+    fm = np.ascontiguousarray(fm * np.linspace(0.5, 1.5, C, dtype=np.float32))
     out, win = ops.roi_crop_pool_fwd(T(fm, dev), T(prop, dev), (14, 14), 2, want_winner=True)
     ro, ra = O.roi_crop_pool(fm, prop, (14, 14), 2)
     np.testing.assert_array_equal(out.cpu().numpy(), ro)
