@@ -180,6 +180,32 @@ __device__ __forceinline__ float rlf(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff) {
+    const f32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff,
+                                           float4 v) {
+    f32x4 t;
+    t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_amdgcn_raw_buffer_store_b128(t, rs, voff, soff, 0);
+}
+// single-instruction maxima (fmaxf() would add a canonicalising v_max per operand)
+__device__ __forceinline__ float vmax2(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+template <bool B> struct BoolTag { static constexpr bool value = B; };
+
 template <int POOL, bool WIN>
 __global__ void __launch_bounds__(256)
 roi_fwd_walk_kernel(const float* __restrict__ fmap, int H, int W, int C, long long sb, long long sh,
@@ -195,6 +221,7 @@ roi_fwd_walk_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
     uint32_t xlo[POOL], xhi[POOL];
     float xfr[POOL];
     bool xok[POOL];
+    bool xall = true;
     const uint32_t chan_off = (uint32_t)(slice * RW_CS + cq * 4) * 4u;
 #pragma unroll
     for (int k = 0; k < POOL; ++k) {
@@ -206,10 +233,18 @@ roi_fwd_walk_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
         xhi[k] = (uint32_t)hi * (uint32_t)sw * 4u + chan_off;
         xfr[k] = fr;
         xok[k] = sx < cw && ok;
+        xall = xall && (xok[k] || sx >= cw);
     }
+    const bool wave_xall = __all(xall);                   // no extrapolated column in this wave
     if (q >= pw) return;
-    const char* img = reinterpret_cast<const char*>(fmap) + (size_t)b * sb * 4;        // uniform
-    const size_t oroi = ((size_t)b * R + r) * (size_t)(ph * pw) * C;                    // uniform
+    // uniform descriptors: this image's feature map; this RoI's output block
+    const uint32_t row_bytes = (uint32_t)sh * 4u;
+    const __amdgpu_buffer_rsrc_t img = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(fmap) + (size_t)b * sb, 0, (uint32_t)H * row_bytes, 0x00020000);
+    const size_t oroi = ((size_t)b * R + r) * (size_t)(ph * pw) * C;
+    const uint32_t orow_bytes = (uint32_t)pw * (uint32_t)C * 4u;
+    const __amdgpu_buffer_rsrc_t obuf = __builtin_amdgcn_make_buffer_rsrc(
+        out + oroi, 0, (uint32_t)ph * orow_bytes, 0x00020000);
     const uint32_t ooff = (uint32_t)q * (uint32_t)C * 4u + chan_off;                   // per thread
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     const int nsy = ph * POOL;
@@ -218,27 +253,34 @@ roi_fwd_walk_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
 
     auto fold = [&](int sy, const float4 (&v)[POOL]) {
         const int ky = sy % POOL;
+        if (WIN) {
 #pragma unroll
-        for (int kx = 0; kx < POOL; ++kx) {
-            const int k = ky * POOL + kx;
-            if (k == 0) {
-                best = v[kx];
-                if (WIN) arg = make_uchar4(0, 0, 0, 0);
-            } else if (WIN) {
-                if (v[kx].x > best.x) { best.x = v[kx].x; arg.x = k; }
-                if (v[kx].y > best.y) { best.y = v[kx].y; arg.y = k; }
-                if (v[kx].z > best.z) { best.z = v[kx].z; arg.z = k; }
-                if (v[kx].w > best.w) { best.w = v[kx].w; arg.w = k; }
-            } else {
-                best.x = fmaxf(best.x, v[kx].x); best.y = fmaxf(best.y, v[kx].y);
-                best.z = fmaxf(best.z, v[kx].z); best.w = fmaxf(best.w, v[kx].w);
+            for (int kx = 0; kx < POOL; ++kx) {
+                const int k = ky * POOL + kx;
+                if (k == 0) {
+                    best = v[kx];
+                    arg = make_uchar4(0, 0, 0, 0);
+                } else {
+                    if (v[kx].x > best.x) { best.x = v[kx].x; arg.x = k; }
+                    if (v[kx].y > best.y) { best.y = v[kx].y; arg.y = k; }
+                    if (v[kx].z > best.z) { best.z = v[kx].z; arg.z = k; }
+                    if (v[kx].w > best.w) { best.w = v[kx].w; arg.w = k; }
+                }
             }
+        } else if (POOL == 1) {
+            best = v[0];
+        } else if (ky == 0) {
+            best.x = vmax2(v[0].x, v[POOL - 1].x); best.y = vmax2(v[0].y, v[POOL - 1].y);
+            best.z = vmax2(v[0].z, v[POOL - 1].z); best.w = vmax2(v[0].w, v[POOL - 1].w);
+        } else {
+            best.x = vmax3(best.x, v[0].x, v[POOL - 1].x); best.y = vmax3(best.y, v[0].y, v[POOL - 1].y);
+            best.z = vmax3(best.z, v[0].z, v[POOL - 1].z); best.w = vmax3(best.w, v[0].w, v[POOL - 1].w);
         }
         if (ky == POOL - 1) {
-            const size_t orow = (oroi + (size_t)(sy / POOL) * pw * C) * 4;             // uniform
-            *reinterpret_cast<float4*>(reinterpret_cast<char*>(out) + orow + ooff) = best;
+            const uint32_t orow = (uint32_t)(sy / POOL) * orow_bytes;                  // uniform
+            buf_store4(obuf, ooff, orow, best);
             if (WIN)
-                *reinterpret_cast<uchar4*>(winner + (orow >> 2) + (ooff >> 2)) = arg;
+                *reinterpret_cast<uchar4*>(winner + oroi + ((orow + ooff) >> 2)) = arg;
         }
     };
 
@@ -252,12 +294,11 @@ roi_fwd_walk_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
             for (int k = 0; k < POOL; ++k) {
                 v[k] = zero;
                 if (lo >= 0 && xok[k]) {
-                    const char* rt = img + (size_t)lo * sh * 4;
-                    const char* rb = img + (size_t)hi * sh * 4;
-                    const float4 top = lerp4(*reinterpret_cast<const float4*>(rt + xlo[k]),
-                                             *reinterpret_cast<const float4*>(rt + xhi[k]), xfr[k]);
-                    const float4 bot = lerp4(*reinterpret_cast<const float4*>(rb + xlo[k]),
-                                             *reinterpret_cast<const float4*>(rb + xhi[k]), xfr[k]);
+                    const uint32_t rt = (uint32_t)lo * row_bytes, rb = (uint32_t)hi * row_bytes;
+                    const float4 top = lerp4(buf_load4(img, xlo[k], rt), buf_load4(img, xhi[k], rt),
+                                             xfr[k]);
+                    const float4 bot = lerp4(buf_load4(img, xlo[k], rb), buf_load4(img, xhi[k], rb),
+                                             xfr[k]);
                     v[k] = lerp4(top, bot, fr);
                 }
             }
@@ -273,15 +314,16 @@ roi_fwd_walk_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
     int sy = 0;
 
     auto load_row = [&](int j, float4 (&ll)[POOL], float4 (&lr)[POOL]) {
-        const char* row = img + (size_t)rl(rw.t_row, j) * sh * 4;                       // uniform
+        const uint32_t roff = (uint32_t)rl(rw.t_row, j) * row_bytes;                    // uniform
 #pragma unroll
         for (int k = 0; k < POOL; ++k) {
-            ll[k] = *reinterpret_cast<const float4*>(row + xlo[k]);
-            lr[k] = *reinterpret_cast<const float4*>(row + xhi[k]);
+            ll[k] = buf_load4(img, xlo[k], roff);
+            lr[k] = buf_load4(img, xhi[k], roff);
         }
     };
     // finish every sample row that needs nothing beyond unique row j
-    auto drain = [&](int j, const float4 (&hc)[POOL], const float4 (&hp)[POOL]) {
+    auto drain = [&](int j, const float4 (&hc)[POOL], const float4 (&hp)[POOL], auto xtag) {
+        constexpr bool XALL = decltype(xtag)::value;
         while (sy < nsy) {
             const int lo = rl(rw.t_lo, sy), hi = rl(rw.t_hi, sy);
             if (lo >= 0 && hi > j) break;
@@ -292,31 +334,39 @@ roi_fwd_walk_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
                 for (int k = 0; k < POOL; ++k) v[k] = zero;
             } else if (lo == j) {
 #pragma unroll
-                for (int k = 0; k < POOL; ++k) v[k] = xok[k] ? lerp4(hc[k], hc[k], fr) : zero;
+                for (int k = 0; k < POOL; ++k) {
+                    v[k] = lerp4(hc[k], hc[k], fr);
+                    if (!XALL && !xok[k]) v[k] = zero;
+                }
             } else {
 #pragma unroll
-                for (int k = 0; k < POOL; ++k) v[k] = xok[k] ? lerp4(hp[k], hc[k], fr) : zero;
+                for (int k = 0; k < POOL; ++k) {
+                    v[k] = lerp4(hp[k], hc[k], fr);
+                    if (!XALL && !xok[k]) v[k] = zero;
+                }
             }
             fold(sy, v);
             ++sy;
         }
     };
     auto step = [&](int j, float4 (&hc)[POOL], const float4 (&hp)[POOL], const float4 (&cl)[POOL],
-                    const float4 (&cr)[POOL], float4 (&nl)[POOL], float4 (&nr_)[POOL]) {
+                    const float4 (&cr)[POOL], float4 (&nl)[POOL], float4 (&nr_)[POOL], auto xtag) {
         load_row(min(j + 1, NR - 1), nl, nr_);          // next row in flight (last row: reloaded)
 #pragma unroll
         for (int k = 0; k < POOL; ++k) hc[k] = lerp4(cl[k], cr[k], xfr[k]);
-        drain(j, hc, hp);
+        drain(j, hc, hp, xtag);
     };
-
-    drain(-1, hA, hB);                                   // leading extrapolated sample rows
-    if (NR > 0) load_row(0, lAl, lAr);
+    auto run = [&](auto xtag) {
+        drain(-1, hA, hB, xtag);                         // leading extrapolated sample rows
+        if (NR > 0) load_row(0, lAl, lAr);
 #pragma unroll 1
-    for (int j = 0; j < NR; j += 2) {
-        step(j, hA, hB, lAl, lAr, lBl, lBr);
-        if (j + 1 < NR) step(j + 1, hB, hA, lBl, lBr, lAl, lAr);
-    }
-    drain(NR, hA, hB);                                   // trailing extrapolated sample rows
+        for (int j = 0; j < NR; j += 2) {
+            step(j, hA, hB, lAl, lAr, lBl, lBr, xtag);
+            if (j + 1 < NR) step(j + 1, hB, hA, lBl, lBr, lAl, lAr, xtag);
+        }
+        drain(NR, hA, hB, xtag);                         // trailing extrapolated sample rows
+    };
+    if (wave_xall) run(BoolTag<true>{}); else run(BoolTag<false>{});
 }
 
 // ---- any-stride fallback: one thread per channel.
@@ -485,8 +535,10 @@ extern "C" int frcnn_roi_crop_pool_fwd(const float* fmap, int B, int H, int W, i
     hipStream_t st = (hipStream_t)stream;
     const bool walk_path = fast && (C % RW_CS) == 0 && crop_h <= RW_MAXCROP &&
                            crop_w <= RW_MAXCROP && (long long)R * (C / RW_CS) <= 0x7FFFFFFFll &&
+                           sb > 0 && sh > 0 && sw > 0 && (long long)(W - 1) * sw + C <= sh &&
+                           (long long)H * sh * 4 < 0x7FFFFFFFll &&
                            (long long)W * sw * 4 + (long long)C * 4 < 0x7FFFFFFFll &&
-                           (long long)(crop_w / pool) * C * 4 < 0x7FFFFFFFll;
+                           (long long)(crop_h / pool) * (crop_w / pool) * C * 4 < 0x7FFFFFFFll;
     if (walk_path) {
         const int nslice = C / RW_CS;
         const int pw = crop_w / pool;
