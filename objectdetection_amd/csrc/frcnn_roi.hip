@@ -328,24 +328,28 @@ roi_fwd_walk_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
             const int lo = rl(rw.t_lo, sy), hi = rl(rw.t_hi, sy);
             if (lo >= 0 && hi > j) break;
             const float fr = rlf(rw.t_fr, sy);
-            float4 v[POOL];
             if (lo < 0) {
+                float4 v[POOL];
 #pragma unroll
                 for (int k = 0; k < POOL; ++k) v[k] = zero;
+                fold(sy, v);
             } else if (lo == j) {
+                float4 v[POOL];
 #pragma unroll
                 for (int k = 0; k < POOL; ++k) {
                     v[k] = lerp4(hc[k], hc[k], fr);
                     if (!XALL && !xok[k]) v[k] = zero;
                 }
+                fold(sy, v);
             } else {
+                float4 v[POOL];
 #pragma unroll
                 for (int k = 0; k < POOL; ++k) {
                     v[k] = lerp4(hp[k], hc[k], fr);
                     if (!XALL && !xok[k]) v[k] = zero;
                 }
+                fold(sy, v);
             }
-            fold(sy, v);
             ++sy;
         }
     };
