@@ -1,0 +1,59 @@
+"""The C-ABI library loads on a CPU-only host and exports every symbol the
+header declares (no compute call is made here)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "frcnn_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(frcnn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from objectdetection_amd import _lib
+    syms = header_symbols()
+    assert len(syms) >= 14
+    for s in syms:
+        assert hasattr(_lib.lib, s), f"{s} declared in include/frcnn_hip.h but not exported"
+    assert sorted(_lib.EXPORTS) == syms, "ctypes signature table and header disagree"
+
+
+def test_status_strings_and_version():
+    from objectdetection_amd import _lib
+    assert _lib.lib.frcnn_abi_version() == 1
+    assert _lib.status_string(0) == "ok"
+    for code in (-1, -2, -3, -4):
+        assert _lib.status_string(code) not in ("ok", "unknown status")
+    assert _lib.status_string(-99) == "unknown status"
+
+
+def test_bad_arguments_are_rejected_without_a_gpu():
+    """Argument checks run before any launch, so they can be exercised here."""
+    from objectdetection_amd import _lib
+    L = _lib.lib
+    assert L.frcnn_nms_workspace_bytes(2, 6000) == 2 * 6000 * 94 * 8
+    assert L.frcnn_nms_workspace_bytes(0, 10) == 0
+    assert L.frcnn_topk(None, 1, 10, 5, None, None, None, None, None, None) == _lib.E_BADARG
+    one = ctypes.c_void_p(16)        # never dereferenced: the size checks fail first
+    assert L.frcnn_topk(one, 1, 10, 11, None, None, one, one, None, None) == _lib.E_BADARG
+    assert L.frcnn_topk(one, 1, 100000, 20000, None, None, one, one, None, None) == _lib.E_UNSUPPORTED
+    assert L.frcnn_nms(one, 1, 100, 0.7, 10, one, None, None, None, 0, None) == _lib.E_WORKSPACE
+    assert L.frcnn_roi_crop_pool_fwd(one, 1, 4, 4, 4, 64, 16, 4, 1, one, 1, 14, 14, 3, one, None,
+                                     None) == _lib.E_BADARG
+    assert L.frcnn_roi_crop_pool_fwd(one, 1, 4, 4, 4, 64, 16, 4, 1, one, 1, 13, 14, 2, one, None,
+                                     None) == _lib.E_BADARG
+    assert L.frcnn_rpn_sample(one, 2, 2, 1, one, 1, 4, one, one, one, None, None, 0, 0, 16, 8,
+                              one, one, one, one, one, one, one, None) == _lib.E_BADARG
+
+
+def test_no_product_module_imports_the_oracle():
+    pkg = os.path.join(ROOT, "objectdetection_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert "oracle" not in src, f"{f} mentions the oracle"

@@ -1,0 +1,57 @@
+"""The N>1 path on CPU: two gloo ranks shard a batch per image, each works on
+its own slice with no data-path collective, and the small per-image results are
+reassembled in image order for reporting."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import frcnn_oracle as O
+from objectdetection_amd import shard
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_images, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        assert shard.rank_world() == (rank, world)
+        d = O.synth_inputs(seed=7, B=n_images, H=8, W=8, A=9, C=4, G=6)
+        a = O.make_anchor(8, 8)
+        score, coord = shard.shard([torch.from_numpy(d["score"]), torch.from_numpy(d["coord"])],
+                                   rank, world)
+        s, e = shard.shard_range(n_images, rank, world)
+        # the per-image unit of work (the CPU oracle stands in for the GPU path here)
+        pc = O.proposal_creator(score.numpy(), coord.numpy(), a, pre_k=200, post_n=40)
+        counts = torch.from_numpy(pc["counts"].astype(np.int64))
+        keep = torch.from_numpy(pc["keep_pos"].astype(np.int64))
+        all_counts = shard.gather_small(counts, n_images)
+        all_keep = shard.gather_small(keep, n_images)
+        # timing reduction used by bench.py: max over ranks
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert t.item() == world
+        if rank == 0:
+            np.save(os.path.join(out_dir, "counts.npy"), all_counts.numpy())
+            np.save(os.path.join(out_dir, "keep.npy"), all_keep.numpy())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one_rank(tmp_path):
+    n_images, world = 5, 2          # ragged: 3 + 2 images
+    mp.spawn(_worker, args=(world, _free_port(), n_images, str(tmp_path)), nprocs=world, join=True)
+    d = O.synth_inputs(seed=7, B=n_images, H=8, W=8, A=9, C=4, G=6)
+    pc = O.proposal_creator(d["score"], d["coord"], O.make_anchor(8, 8), pre_k=200, post_n=40)
+    np.testing.assert_array_equal(np.load(tmp_path / "counts.npy"), pc["counts"])
+    np.testing.assert_array_equal(np.load(tmp_path / "keep.npy"), pc["keep_pos"])
