@@ -46,72 +46,32 @@ topk_kernel(const float* __restrict__ scores, int N, int K, int n_pad,
 // NMS
 // =========================================================================
 // IoU of the TF NMS kernel: corners re-ordered, area <= 0 on either side -> 0,
-// inter = max(dy,0)*max(dx,0), iou = inter / (area_i + area_j - inter); a pair
-// suppresses when iou > thr (strict).
-struct NBox { float y0, x0, y1, x1, area; };
+// inter = max(dy,0)*max(dx,0), iou = inter / (area_i + area_j - inter); box i
+// (higher score) suppresses box j when iou > thr (strict).
+//
+// Layout.  Candidates are cut into blocks of 64 in score order.  maskT[b][ib][j]
+// (u64) holds, for column box j, one bit per row box of row block ib: bit r set
+// <=> box ib*64+r suppresses box j (only rows before j can be set).  The greedy
+// scan of column block jb needs the words of row blocks 0..jb only, and those
+// loads do not depend on the scan state, so they stream.
+//
+// Work is issued in chunks of column blocks: mask kernel for the chunk (all row
+// blocks up to the column block), then scan kernel for the chunk.  An image
+// that has collected post_n boxes raises its `done` flag and every later block
+// of that image returns at once, so the pair tests actually executed are about
+// (last candidate examined)^2 / 2 instead of K^2 / 2.
+struct NBox { float y0, x0, y1, x1, area, t; };          // t = thr_lo * area
 
-__device__ __forceinline__ NBox norm_box(float4 v) {
+__device__ __forceinline__ NBox norm_box(float4 v, float thr_lo) {
     NBox n;
     n.y0 = fminf(v.x, v.z); n.y1 = fmaxf(v.x, v.z);
     n.x0 = fminf(v.y, v.w); n.x1 = fmaxf(v.y, v.w);
     n.area = (n.y1 - n.y0) * (n.x1 - n.x0);
+    n.t = thr_lo * n.area;
     return n;
 }
 
-// Exact evaluation of  (inter / u > thr)  that divides only inside a narrow
-// band around the threshold: outside it the comparison of inter with thr*u is
-// already decided with a margin far above the rounding of the product and of
-// the quotient.
-__device__ __forceinline__ bool iou_over(const NBox& a, const NBox& b, float thr, float thr_lo,
-                                         float thr_hi) {
-    const float iy0 = fmaxf(a.y0, b.y0), ix0 = fmaxf(a.x0, b.x0);
-    const float iy1 = fminf(a.y1, b.y1), ix1 = fminf(a.x1, b.x1);
-    const float inter = fmaxf(iy1 - iy0, 0.0f) * fmaxf(ix1 - ix0, 0.0f);
-    const float u = a.area + b.area - inter;
-    const bool areas = a.area > 0.0f && b.area > 0.0f;
-    const float lo = u * thr_lo, hi = u * thr_hi;
-    bool over;
-    if (lo > 1e-30f && inter > hi) over = true;
-    else if (lo > 1e-30f && inter < lo) over = false;
-    else over = (inter / u) > thr;
-    return areas && over;
-}
-
-// Bitmask kernel.  Workgroup = 4 waves; all share one block of 64 "row" boxes
-// (higher score) staged in LDS, each wave owns one block of 64 "column" boxes
-// (one per lane).  For each row the wave ballots the suppress predicate: the
-// 64-bit result is that row's mask word for this column block.
-// mask[b][i][cb] bit l  <=>  box i suppresses box cb*64+l  (only j > i set).
-__global__ void __launch_bounds__(256)
-nms_mask_kernel(const float4* __restrict__ boxes, int K, int CB, float thr, float thr_lo,
-                float thr_hi, unsigned long long* __restrict__ mask) {
-    const int ib = blockIdx.y;
-    const int b = blockIdx.z;
-    const int jb0 = blockIdx.x * 4;
-    if (jb0 + 3 < ib) return;                       // whole group left of the diagonal
-    __shared__ NBox s_row[64];
-    const float4* bx = boxes + (size_t)b * K;
-    if (threadIdx.x < 64) {
-        const int i = ib * 64 + threadIdx.x;
-        s_row[threadIdx.x] = norm_box(i < K ? bx[i] : make_float4(0.f, 0.f, 0.f, 0.f));
-    }
-    __syncthreads();
-    const int jb = jb0 + wave_id();
-    if (jb < ib || jb >= CB) return;                // wave-uniform
-    const int lane = lane_id();
-    const int j = jb * 64 + lane;
-    const NBox cb = norm_box(j < K ? bx[j] : make_float4(0.f, 0.f, 0.f, 0.f));
-    unsigned long long mine = 0ull;
-#pragma unroll 4
-    for (int r = 0; r < 64; ++r) {
-        const int i = ib * 64 + r;
-        const bool p = (j > i) && (j < K) && iou_over(s_row[r], cb, thr, thr_lo, thr_hi);
-        const unsigned long long w = __ballot(p);
-        if (lane == r) mine = w;
-    }
-    const int i = ib * 64 + lane;
-    if (i < K) mask[((size_t)b * K + i) * CB + jb] = mine;
-}
+constexpr float NMS_TINY_AREA = 1e-18f;
 
 __device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
     const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)v);
@@ -119,78 +79,144 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
     return ((unsigned long long)hi << 32) | lo;
 }
 
-// One wave per image walks the candidates in score order, 64 at a time.
-// rem[] (LDS) = union of the mask rows of every box kept so far.
-__global__ void __launch_bounds__(64)
-nms_scan_kernel(const float4* __restrict__ boxes, const unsigned long long* __restrict__ mask,
-                int K, int CB, int post_n, float4* __restrict__ proposed,
+// One wave = one 64x64 tile: lane = row box (registers), the 64 column boxes sit
+// in LDS.  Per column: a 3-instruction conservative filter
+//     inter*(1+thr) > thr*(1-4e-6)*(area_i+area_j)
+// (implied by iou > thr with a margin far above float rounding), and only when
+// some lane passes it the exact division; the wave ballot of the predicate is
+// the column's mask word.
+template <bool DIAG>
+__device__ __forceinline__ unsigned long long mask_tile(const NBox& a, float c1, const NBox* cols,
+                                                        float thr, int lane) {
+    unsigned long long mine = 0ull;
+#pragma unroll 8
+    for (int c = 0; c < 64; ++c) {
+        const NBox cb = cols[c];
+        const float iy0 = fmaxf(a.y0, cb.y0), ix0 = fmaxf(a.x0, cb.x0);
+        const float iy1 = fminf(a.y1, cb.y1), ix1 = fminf(a.x1, cb.x1);
+        const float inter = fmaxf(iy1 - iy0, 0.0f) * fmaxf(ix1 - ix0, 0.0f);
+        bool p = inter * c1 > a.t + cb.t;
+        if (DIAG) p = p && (c > lane);
+        if (__any(p)) {
+            const float u = a.area + cb.area - inter;
+            p = p && (a.area > 0.0f) && (cb.area > 0.0f) && (inter / u > thr);
+        }
+        const unsigned long long w = __ballot(p);
+        if (lane == c) mine = w;
+    }
+    return mine;
+}
+
+__global__ void __launch_bounds__(256)
+nms_mask_kernel(const float4* __restrict__ boxes, int K, int CB, int jb_begin, float thr, float c1,
+                float thr_lo, const int* __restrict__ done, unsigned long long* __restrict__ maskT) {
+    const int b = blockIdx.z;
+    const int jb = jb_begin + blockIdx.y;
+    const int ib0 = blockIdx.x * 4;
+    if (ib0 > jb || done[b]) return;                   // block-uniform
+    __shared__ NBox s_col[64];
+    const float4* bx = boxes + (size_t)b * K;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (threadIdx.x < 64) {
+        const int j = jb * 64 + threadIdx.x;
+        s_col[threadIdx.x] = norm_box(j < K ? bx[j] : zero4, thr_lo);
+    }
+    __syncthreads();
+    const int ib = ib0 + wave_id();
+    if (ib > jb) return;                               // wave-uniform
+    const int lane = lane_id();
+    const int i = ib * 64 + lane;
+    const NBox a = norm_box(i < K ? bx[i] : zero4, thr_lo);
+    // a tiny row area could underflow the filter's products: +inf makes the filter pass
+    // whenever the boxes intersect, and the exact test decides
+    const float c1l = a.area < NMS_TINY_AREA ? __builtin_inff() : c1;
+    const unsigned long long mine = (ib == jb) ? mask_tile<true>(a, c1l, s_col, thr, lane)
+                                               : mask_tile<false>(a, c1l, s_col, thr, lane);
+    maskT[((size_t)b * CB + ib) * ((size_t)CB * 64) + (size_t)jb * 64 + lane] = mine;
+}
+
+// One workgroup (4 waves) per image walks the chunk's column blocks in order.
+// kept[] (LDS) = keep bits of every block so far.  For block jb the waves split
+// the row blocks 0..jb-1: a column is dead if any (word & kept[ib]) is non-zero;
+// wave 0 then resolves the block's own 64x64 triangle serially and emits.
+__global__ void __launch_bounds__(256)
+nms_scan_kernel(const float4* __restrict__ boxes, const unsigned long long* __restrict__ maskT,
+                int K, int CB, int jb_begin, int jb_end, int post_n,
+                unsigned long long* __restrict__ kept_g, int* __restrict__ count_g,
+                int* __restrict__ done, float4* __restrict__ proposed,
                 int32_t* __restrict__ keep_pos, int32_t* __restrict__ keep_count) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    unsigned long long* rem = reinterpret_cast<unsigned long long*>(smem);
+    unsigned long long* kept = reinterpret_cast<unsigned long long*>(smem);     // CB words
+    unsigned long long* deadw = kept + CB;                                      // 4 words
+    int* s_cnt = reinterpret_cast<int*>(deadw + 4);
     const int b = blockIdx.x;
-    const int lane = threadIdx.x;
+    if (done[b]) return;                               // block-uniform
+    const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
     const float4* bx = boxes + (size_t)b * K;
-    const unsigned long long* mk = mask + (size_t)b * K * CB;
+    const size_t KP = (size_t)CB * 64;
+    const unsigned long long* mk = maskT + (size_t)b * CB * KP;
+    unsigned long long* kg = kept_g + (size_t)b * CB;
     float4* prop = proposed + (size_t)b * post_n;
     int32_t* kp = keep_pos ? keep_pos + (size_t)b * post_n : nullptr;
-    for (int w = lane; w < CB; w += 64) rem[w] = 0ull;
-    __builtin_amdgcn_wave_barrier();
-    int kept = 0;
+    for (int w = tid; w < jb_begin; w += 256) kept[w] = kg[w];
+    if (tid == 0) *s_cnt = count_g[b];
+    __syncthreads();
+    int jb = jb_begin;
 #pragma unroll 1
-    for (int ib = 0; ib < CB && kept < post_n; ++ib) {
-        const int i0 = ib * 64;
-        const int i = i0 + lane;
-        const unsigned long long diag = i < K ? mk[(size_t)i * CB + ib] : 0ull;
-        const int nvalid = K - i0 < 64 ? K - i0 : 64;
-        const unsigned long long vmask = nvalid == 64 ? ~0ull : ((1ull << nvalid) - 1ull);
-        unsigned long long alive = uniform64(~rem[ib] & vmask);
-        unsigned long long keptmask = 0ull;
-        int room = post_n - kept;
-        while (alive != 0ull && room > 0) {          // wave-uniform
-            const int r = __ffsll((long long)alive) - 1;
-            keptmask |= 1ull << r;
-            --room;
-            const unsigned long long d =
-                ((unsigned long long)__builtin_amdgcn_readlane((int)(diag >> 32), r) << 32) |
-                (unsigned int)__builtin_amdgcn_readlane((int)diag, r);
-            alive &= ~(d | (1ull << r));
-        }
-        // emit the kept boxes of this block
-        if ((keptmask >> lane) & 1ull) {
-            const int slot = kept + __popcll(keptmask & lanemask_lt());
-            float4 v = bx[i];
-            v.x = clip01(v.x); v.y = clip01(v.y); v.z = clip01(v.z); v.w = clip01(v.w);
-            prop[slot] = v;
-            if (kp) kp[slot] = i;
-        }
-        kept += __popcll(keptmask);
-        if (kept >= post_n) break;
-        // fold the kept rows into rem[] for the column blocks still ahead
-        for (int w = ib + 1 + lane; w < CB; w += 64) {
-            unsigned long long acc = 0ull;
-            unsigned long long km = keptmask;
-            while (km != 0ull) {                     // wave-uniform
-                int r0 = __ffsll((long long)km) - 1; km &= km - 1ull;
-                int r1 = -1, r2 = -1, r3 = -1;
-                if (km) { r1 = __ffsll((long long)km) - 1; km &= km - 1ull; }
-                if (km) { r2 = __ffsll((long long)km) - 1; km &= km - 1ull; }
-                if (km) { r3 = __ffsll((long long)km) - 1; km &= km - 1ull; }
-                const unsigned long long a0 = mk[(size_t)(i0 + r0) * CB + w];
-                const unsigned long long a1 = r1 >= 0 ? mk[(size_t)(i0 + r1) * CB + w] : 0ull;
-                const unsigned long long a2 = r2 >= 0 ? mk[(size_t)(i0 + r2) * CB + w] : 0ull;
-                const unsigned long long a3 = r3 >= 0 ? mk[(size_t)(i0 + r3) * CB + w] : 0ull;
-                acc |= a0 | a1 | a2 | a3;
+    for (; jb < jb_end; ++jb) {
+        const int count = *s_cnt;
+        if (count >= post_n) break;                    // block-uniform
+        const int j0 = jb * 64;
+        const unsigned long long* col = mk + j0 + lane;
+        const unsigned long long diag = wave == 0 ? col[(size_t)jb * KP] : 0ull;
+        unsigned long long hit = 0ull;
+#pragma unroll 8
+        for (int ib = wave; ib < jb; ib += 4) hit |= col[(size_t)ib * KP] & kept[ib];
+        const unsigned long long dead = __ballot(hit != 0ull);
+        if (lane == 0) deadw[wave] = dead;
+        __syncthreads();
+        if (wave == 0) {
+            const int nvalid = K - j0 < 64 ? K - j0 : 64;
+            const unsigned long long vmask = nvalid == 64 ? ~0ull : ((1ull << nvalid) - 1ull);
+            unsigned long long alive = uniform64(~(deadw[0] | deadw[1] | deadw[2] | deadw[3]) & vmask);
+            unsigned long long keptmask = 0ull;
+            int room = post_n - count;
+            while (alive != 0ull && room > 0) {        // wave-uniform
+                const int r = __ffsll((long long)alive) - 1;
+                keptmask |= 1ull << r;
+                --room;
+                const unsigned long long sup = __ballot(((diag >> r) & 1ull) != 0ull);
+                alive &= ~(sup | (1ull << r));
             }
-            rem[w] |= acc;
+            if ((keptmask >> lane) & 1ull) {
+                const int slot = count + __popcll(keptmask & lanemask_lt());
+                float4 v = bx[j0 + lane];
+                v.x = clip01(v.x); v.y = clip01(v.y); v.z = clip01(v.z); v.w = clip01(v.w);
+                prop[slot] = v;
+                if (kp) kp[slot] = j0 + lane;
+            }
+            if (lane == 0) {
+                kept[jb] = keptmask;
+                *s_cnt = count + __popcll(keptmask);
+            }
         }
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
     }
-    // zero padding (tf.image.combined_non_max_suppression pads boxes with 0)
-    for (int s = kept + lane; s < post_n; s += 64) {
-        prop[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (kp) kp[s] = -1;
+    // persist the state for the next chunk; finish the image if it is complete
+    for (int w = jb_begin + tid; w < jb; w += 256) kg[w] = kept[w];
+    const int count = *s_cnt;
+    if (count >= post_n || jb_end >= CB) {
+        // zero padding (tf.image.combined_non_max_suppression pads boxes with 0)
+        for (int s = count + tid; s < post_n; s += 256) {
+            prop[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kp) kp[s] = -1;
+        }
+        if (tid == 0) {
+            done[b] = 1;
+            if (keep_count) keep_count[b] = count;
+        }
     }
-    if (keep_count && lane == 0) keep_count[b] = kept;
+    if (tid == 0) count_g[b] = count;
 }
 
 }  // namespace frcnn
@@ -219,10 +245,16 @@ extern "C" int frcnn_topk(const float* scores, int B, int N, int K, const float*
     return FRCNN_OK;
 }
 
+// workspace = maskT [B][CB][CB*64] u64 | kept [B][CB] u64 | count [B] i32 | done [B] i32
+static size_t nms_mask_bytes(int B, int K) {
+    const size_t CB = ((size_t)K + 63) / 64;
+    return (size_t)B * CB * CB * 64 * sizeof(unsigned long long);
+}
+
 extern "C" size_t frcnn_nms_workspace_bytes(int B, int K) {
     if (B <= 0 || K <= 0) return 0;
     const size_t CB = ((size_t)K + 63) / 64;
-    return (size_t)B * (size_t)K * CB * sizeof(unsigned long long);
+    return nms_mask_bytes(B, K) + (size_t)B * CB * 8 + (size_t)B * 8;
 }
 
 extern "C" int frcnn_nms(const float* boxes, int B, int K, float iou_threshold, int post_n,
@@ -234,21 +266,34 @@ extern "C" int frcnn_nms(const float* boxes, int B, int K, float iou_threshold, 
     if ((reinterpret_cast<uintptr_t>(workspace) & 7u) != 0) return FRCNN_E_BADARG;
     const int CB = (K + 63) / 64;
     if (CB > 65535 || B > 65535) return FRCNN_E_UNSUPPORTED;
-    if ((size_t)CB * 8 > 150 * 1024) return FRCNN_E_UNSUPPORTED;
-    unsigned long long* mask = reinterpret_cast<unsigned long long*>(workspace);
-    // band edges for the division-free fast path of iou_over()
-    const float thr_lo = iou_threshold * 0.999998f;
-    const float thr_hi = iou_threshold * 1.000002f;
-    FRCNN_LAUNCH(nms_mask_kernel, dim3((CB + 3) / 4, CB, B), dim3(256), 0,
-                       (hipStream_t)stream, reinterpret_cast<const float4*>(boxes), K, CB,
-                       iou_threshold, thr_lo, thr_hi, mask);
-    const size_t lds = (size_t)CB * 8;
+    const size_t lds = (size_t)CB * 8 + 4 * 8 + 16;
+    if (lds > 150 * 1024) return FRCNN_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = reinterpret_cast<char*>(workspace);
+    unsigned long long* maskT = reinterpret_cast<unsigned long long*>(ws);
+    unsigned long long* kept = reinterpret_cast<unsigned long long*>(ws + nms_mask_bytes(B, K));
+    int* count = reinterpret_cast<int*>(ws + nms_mask_bytes(B, K) + (size_t)B * CB * 8);
+    int* done = count + B;
+    if (hipMemsetAsync(count, 0, (size_t)B * 8, st) != hipSuccess) return FRCNN_E_LAUNCH;
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(nms_scan_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return FRCNN_E_LAUNCH;
-    FRCNN_LAUNCH(nms_scan_kernel, dim3(B), dim3(64), lds, (hipStream_t)stream,
-                       reinterpret_cast<const float4*>(boxes), mask, K, CB, post_n,
-                       reinterpret_cast<float4*>(proposed), keep_pos, keep_count);
+    // filter constants: iou > thr  =>  inter*(1+thr) > thr*(1-4e-6)*(area_i+area_j)
+    const float c1 = 1.0f + iou_threshold;
+    const float thr_lo = iou_threshold * 0.999996f;
+    // chunks of column blocks: 16,16,32,32,64,64,... (early chunks small: most images stop early)
+    int jb = 0, width = 16, n = 0;
+    while (jb < CB) {
+        const int je = jb + width < CB ? jb + width : CB;
+        FRCNN_LAUNCH(nms_mask_kernel, dim3((je + 3) / 4, je - jb, B), dim3(256), 0, st,
+                     reinterpret_cast<const float4*>(boxes), K, CB, jb, iou_threshold, c1, thr_lo,
+                     done, maskT);
+        FRCNN_LAUNCH(nms_scan_kernel, dim3(B), dim3(256), lds, st,
+                     reinterpret_cast<const float4*>(boxes), maskT, K, CB, jb, je, post_n, kept,
+                     count, done, reinterpret_cast<float4*>(proposed), keep_pos, keep_count);
+        jb = je;
+        if (++n % 2 == 0 && width < 4096) width *= 2;
+    }
     return FRCNN_OK;
 }
