@@ -282,7 +282,7 @@ extern "C" int frcnn_nms(const float* boxes, int B, int K, float iou_threshold, 
     // filter constants: iou > thr  =>  inter*(1+thr) > thr*(1-4e-6)*(area_i+area_j)
     const float c1 = 1.0f + iou_threshold;
     const float thr_lo = iou_threshold * 0.999996f;
-    // chunks of column blocks: 16,16,32,32,64,64,... (early chunks small: most images stop early)
+    // chunks of column blocks: 8 x 16, then 32,32,64,64,... (fine early: most images stop early)
     int jb = 0, width = 16, n = 0;
     while (jb < CB) {
         const int je = jb + width < CB ? jb + width : CB;
@@ -293,7 +293,7 @@ extern "C" int frcnn_nms(const float* boxes, int B, int K, float iou_threshold, 
                      reinterpret_cast<const float4*>(boxes), maskT, K, CB, jb, je, post_n, kept,
                      count, done, reinterpret_cast<float4*>(proposed), keep_pos, keep_count);
         jb = je;
-        if (++n % 2 == 0 && width < 4096) width *= 2;
+        if (++n >= 8 && n % 2 == 0 && width < 4096) width *= 2;
     }
     return FRCNN_OK;
 }

@@ -210,7 +210,7 @@ template <int POOL, bool WIN>
 __global__ void __launch_bounds__(256)
 roi_fwd_walk_kernel(const float* __restrict__ fmap, int H, int W, int C, long long sb, long long sh,
                     long long sw, const float4* __restrict__ rois, int R, int ch, int cw,
-                    int nslice, float* __restrict__ out, uint8_t* __restrict__ winner) {
+                    int nslice, int nsub, float* __restrict__ out, uint8_t* __restrict__ winner) {
     const int tid = threadIdx.x;
     const int slice = blockIdx.x % nslice, r = blockIdx.x / nslice, b = blockIdx.y;
     const float4 box = rois[(size_t)b * R + r];
@@ -222,7 +222,7 @@ roi_fwd_walk_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
     float xfr[POOL];
     bool xok[POOL];
     bool xall = true;
-    const uint32_t chan_off = (uint32_t)(slice * RW_CS + cq * 4) * 4u;
+    const uint32_t chan_off = (uint32_t)(slice * nsub * RW_CS + cq * 4) * 4u;
 #pragma unroll
     for (int k = 0; k < POOL; ++k) {
         int lo = 0, hi = 0, ok = 0;
@@ -250,6 +250,7 @@ roi_fwd_walk_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
     const int nsy = ph * POOL;
     float4 best = zero;
     uchar4 arg = make_uchar4(0, 0, 0, 0);
+    uint32_t sub_off = 0;                 // byte offset of the 64-channel sub-slice in progress
 
     auto fold = [&](int sy, const float4 (&v)[POOL]) {
         const int ky = sy % POOL;
@@ -277,7 +278,7 @@ roi_fwd_walk_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
             best.z = vmax3(best.z, v[0].z, v[POOL - 1].z); best.w = vmax3(best.w, v[0].w, v[POOL - 1].w);
         }
         if (ky == POOL - 1) {
-            const uint32_t orow = (uint32_t)(sy / POOL) * orow_bytes;                  // uniform
+            const uint32_t orow = (uint32_t)(sy / POOL) * orow_bytes + sub_off;        // uniform
             buf_store4(obuf, ooff, orow, best);
             if (WIN)
                 *reinterpret_cast<uchar4*>(winner + oroi + ((orow + ooff) >> 2)) = arg;
@@ -286,6 +287,7 @@ roi_fwd_walk_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
 
     if (!rw.walk) {
         // flipped box: rows are not ascending; fetch every corner directly
+        for (int sub = 0; sub < nsub; ++sub, sub_off += RW_CS * 4)
         for (int sy = 0; sy < nsy; ++sy) {
             const int lo = rl(rw.t_lo, sy), hi = rl(rw.t_hi, sy);
             const float fr = rlf(rw.t_fr, sy);
@@ -294,7 +296,7 @@ roi_fwd_walk_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
             for (int k = 0; k < POOL; ++k) {
                 v[k] = zero;
                 if (lo >= 0 && xok[k]) {
-                    const uint32_t rt = (uint32_t)lo * row_bytes, rb = (uint32_t)hi * row_bytes;
+                    const uint32_t rt = (uint32_t)lo * row_bytes + sub_off, rb = (uint32_t)hi * row_bytes + sub_off;
                     const float4 top = lerp4(buf_load4(img, xlo[k], rt), buf_load4(img, xhi[k], rt),
                                              xfr[k]);
                     const float4 bot = lerp4(buf_load4(img, xlo[k], rb), buf_load4(img, xhi[k], rb),
@@ -314,7 +316,7 @@ roi_fwd_walk_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
     int sy = 0;
 
     auto load_row = [&](int j, float4 (&ll)[POOL], float4 (&lr)[POOL]) {
-        const uint32_t roff = (uint32_t)rl(rw.t_row, j) * row_bytes;                    // uniform
+        const uint32_t roff = (uint32_t)rl(rw.t_row, j) * row_bytes + sub_off;          // uniform
 #pragma unroll
         for (int k = 0; k < POOL; ++k) {
             ll[k] = buf_load4(img, xlo[k], roff);
@@ -361,6 +363,7 @@ roi_fwd_walk_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
         drain(j, hc, hp, xtag);
     };
     auto run = [&](auto xtag) {
+        sy = 0;
         drain(-1, hA, hB, xtag);                         // leading extrapolated sample rows
         if (NR > 0) load_row(0, lAl, lAr);
 #pragma unroll 1
@@ -370,7 +373,10 @@ roi_fwd_walk_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
         }
         drain(NR, hA, hB, xtag);                         // trailing extrapolated sample rows
     };
-    if (wave_xall) run(BoolTag<true>{}); else run(BoolTag<false>{});
+#pragma unroll 1
+    for (int sub = 0; sub < nsub; ++sub, sub_off += RW_CS * 4) {
+        if (wave_xall) run(BoolTag<true>{}); else run(BoolTag<false>{});
+    }
 }
 
 // ---- any-stride fallback: one thread per channel.
@@ -544,12 +550,15 @@ extern "C" int frcnn_roi_crop_pool_fwd(const float* fmap, int B, int H, int W, i
                            (long long)W * sw * 4 + (long long)C * 4 < 0x7FFFFFFFll &&
                            (long long)(crop_h / pool) * (crop_w / pool) * C * 4 < 0x7FFFFFFFll;
     if (walk_path) {
-        const int nslice = C / RW_CS;
+        // 64-channel sub-slices walked by one workgroup.  2, 4 and 8 measured no faster than 1
+        // (the kernel is bound by the texture addresser, not by the per-RoI set-up).
+        const int nsub = 1;
+        const int nslice = C / (RW_CS * nsub);
         const int pw = crop_w / pool;
         const dim3 g3((unsigned)(R * nslice), B), b3(64 * ((pw + 3) / 4));
 #define FRCNN_WALK(P, WN)                                                                       \
     FRCNN_LAUNCH((roi_fwd_walk_kernel<P, WN>), g3, b3, 0, st, fmap, H, W, C, (long long)sb,     \
-                 (long long)sh, (long long)sw, rb, R, crop_h, crop_w, nslice, out, winner)
+                 (long long)sh, (long long)sw, rb, R, crop_h, crop_w, nslice, nsub, out, winner)
         if (pool == 2) { if (winner) FRCNN_WALK(2, true); else FRCNN_WALK(2, false); }
         else           { FRCNN_WALK(1, false); }
 #undef FRCNN_WALK
