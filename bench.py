@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--channels", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inference", action="store_true", help="skip the training-only stages")
+    ap.add_argument("--backend", default="nccl",
+                    help="torch.distributed backend (gloo lets several ranks rehearse on one GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -103,8 +105,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
+        ndev = torch.cuda.device_count()
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local))
+        else:
+            local = local % max(ndev, 1)
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
 
@@ -132,7 +139,8 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -170,7 +178,7 @@ def main():
                 "mean_kept_proposals": kept,
             },
             "roofline": {
-                "kernel": "roi_fwd_cl_kernel<2>",
+                "kernel": "roi_fwd_walk_kernel<2,false>",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,

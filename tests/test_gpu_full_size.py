@@ -1,0 +1,156 @@
+"""Parity at the full sizes of the benchmark configurations.
+
+Config 1: 600x1000 image, 37x62x9 anchors, G=42, 12k -> 2k NMS, C=512  (direct oracle comparison)
+Config 2: ship detector, 768x768 -> 48x48x12, batch 16, <=50 small GT   (direct, 2 of 16 images + properties)
+Config 3: 1333x800 -> 50x83x15, G=200, 100,000 NMS inputs               (direct oracle comparison + properties)
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import frcnn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def T(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def nms_properties(boxes, keep, count, thr, post_n):
+    """Size-independent checks on a keep list (numpy, vectorised)."""
+    n = int(count)
+    k = keep[:n].astype(np.int64)
+    assert (np.diff(k) > 0).all(), "keep positions ascending"
+    kb = boxes[k]
+    # kept boxes do not suppress each other
+    for i in range(0, n, 256):
+        iou = np.stack([O.nms_iou(kb[j], kb[:j]) if j else np.zeros(0, np.float32)
+                        for j in range(i, min(n, i + 8))], 0) if False else None
+    sub = kb[: min(n, 400)]
+    for j in range(1, sub.shape[0]):
+        assert not (O.nms_iou(sub[j], sub[:j]) > np.float32(thr)).any()
+    # every skipped candidate before the last kept one is suppressed by an earlier kept box
+    if n:
+        last = int(k[-1]) if n < post_n else int(k[-1])
+        skipped = np.setdiff1d(np.arange(last), k)[:300]
+        for s in skipped:
+            earlier = kb[k < s]
+            assert (O.nms_iou(boxes[s], earlier) > np.float32(thr)).any()
+
+
+def test_config1_full_size_direct(dev):
+    from objectdetection_amd.config import PathConfig
+    from objectdetection_amd.pipeline import RegionProposalPath
+    cfg = PathConfig(H=37, W=62, base_w=1000.0, base_h=600.0, G=42, pre_k=12000, post_n=2000)
+    B, C = 2, 512
+    d = O.synth_inputs(seed=101, B=B, H=cfg.H, W=cfg.W, A=cfg.A, C=C, G=cfg.G)
+    path = RegionProposalPath(cfg, B, C, dev, train=True, want_winner=True)
+    path.run(T(d["fmap"], dev), T(d["score"], dev), T(d["coord"], dev), T(d["gt"], dev),
+             T(d["label"], dev), seed=9)
+    a = O.make_anchor(cfg.H, cfg.W, cfg.scales, cfg.ratios, cfg.base_w, cfg.base_h)
+    assert a.shape[0] * a.shape[1] * a.shape[2] == 20646
+    np.testing.assert_array_equal(path.anchor.cpu().numpy(), a)
+    _, ri = O.top_k(d["score"].reshape(B, -1), cfg.pre_k)
+    np.testing.assert_array_equal(path.top_idx.cpu().numpy(), ri)
+    cand = path.cand.cpu().numpy()
+    ref_cand = np.take_along_axis(O.inverse_trans(a, d["coord"]).reshape(B, -1, 4),
+                                  ri.astype(np.int64)[..., None], 1)
+    np.testing.assert_allclose(cand, ref_cand, rtol=1e-5, atol=1e-7)
+    proposed, keep, counts = O.combined_nms(cand, None, cfg.post_n, cfg.nms_thr)
+    np.testing.assert_array_equal(path.keep_pos.cpu().numpy(), keep)
+    np.testing.assert_array_equal(path.proposed.cpu().numpy(), proposed)
+    ro, ra = O.roi_crop_pool(d["fmap"], proposed, cfg.crop, cfg.pool)
+    np.testing.assert_array_equal(path.pooled.cpu().numpy(), ro)
+    np.testing.assert_array_equal(path.winner.cpu().numpy(), ra)
+    lab = O.label_proposals(proposed, d["gt"], d["label"])
+    np.testing.assert_array_equal(path.p_label.cpu().numpy(), lab["p_iou"])
+    np.testing.assert_array_equal(path.tindex.cpu().numpy(), O.sample_proposals(lab["p_iou"], seed=9))
+    for b in range(B):
+        ref = O.patch_batch(dict(image=None, bbox=d["gt"][b], label=d["label"][b]), a, seed=9,
+                            image_index=b)
+        np.testing.assert_array_equal(path.rpn["pos"][b].cpu().numpy(), ref[5])
+        np.testing.assert_array_equal(path.rpn["gt_list"][b].cpu().numpy(), ref[4])
+
+
+def test_config2_ship_batch16(dev):
+    from objectdetection_amd.config import PathConfig
+    from objectdetection_amd.pipeline import RegionProposalPath
+    cfg = PathConfig(H=48, W=48, scales=(32, 64, 128, 256), base_w=500.0, base_h=500.0, G=50,
+                     pre_k=6000, post_n=1500)
+    B, C = 16, 128
+    d = O.synth_inputs(seed=202, B=B, H=cfg.H, W=cfg.W, A=cfg.A, C=C, G=cfg.G,
+                       gt_side=(0.01, 0.06))
+    path = RegionProposalPath(cfg, B, C, dev, train=True)
+    path.run(T(d["fmap"], dev), T(d["score"], dev), T(d["coord"], dev), T(d["gt"], dev),
+             T(d["label"], dev), seed=4)
+    a = O.make_anchor(cfg.H, cfg.W, cfg.scales, cfg.ratios, cfg.base_w, cfg.base_h)
+    assert a.reshape(-1, 4).shape[0] == 27648
+    _, ri = O.top_k(d["score"].reshape(B, -1), cfg.pre_k)
+    np.testing.assert_array_equal(path.top_idx.cpu().numpy(), ri)
+    cand = path.cand.cpu().numpy()
+    keep = path.keep_pos.cpu().numpy()
+    cnt = path.keep_count.cpu().numpy()
+    prop = path.proposed.cpu().numpy()
+    for b in (0, 15):                                         # direct on two images
+        rp, rk, rc = O.combined_nms(cand[b:b + 1], None, cfg.post_n, cfg.nms_thr)
+        np.testing.assert_array_equal(keep[b], rk[0])
+        np.testing.assert_array_equal(prop[b], rp[0])
+        ro, _ = O.roi_crop_pool(d["fmap"][b:b + 1], rp, cfg.crop, cfg.pool)
+        np.testing.assert_array_equal(path.pooled[b].cpu().numpy(), ro[0])
+        ref = O.patch_batch(dict(image=None, bbox=d["gt"][b], label=d["label"][b]), a, seed=4,
+                            image_index=b)
+        np.testing.assert_array_equal(path.rpn["pos"][b].cpu().numpy(), ref[5])
+    for b in range(B):                                        # properties on all 16
+        nms_properties(cand[b], keep[b], cnt[b], cfg.nms_thr, cfg.post_n)
+        assert (prop[b, cnt[b]:] == 0).all()
+    lab = O.label_proposals(prop, d["gt"], d["label"])
+    np.testing.assert_array_equal(path.p_label.cpu().numpy(), lab["p_iou"])
+    np.testing.assert_array_equal(path.tindex.cpu().numpy(), O.sample_proposals(lab["p_iou"], seed=4))
+
+
+def test_config3_dense_100k_nms(dev):
+    from objectdetection_amd import ops
+    rng = np.random.default_rng(303)
+    K, post_n = 100_000, 2000
+    cy, cx = rng.uniform(0, 1, K), rng.uniform(0, 1, K)
+    h, w = np.exp(rng.uniform(np.log(0.01), np.log(0.3), K)), np.exp(rng.uniform(np.log(0.01), np.log(0.3), K))
+    boxes = np.clip(np.stack([cy - h / 2, cx - w / 2, cy + h / 2, cx + w / 2], 1), 0, 1)
+    boxes = boxes.astype(np.float32)[None]
+    prop, keep, cnt = ops.nms(T(boxes, dev), 0.7, post_n)
+    rp, rk, rc = O.combined_nms(boxes, None, post_n, 0.7)
+    np.testing.assert_array_equal(cnt.cpu().numpy(), rc)
+    np.testing.assert_array_equal(keep.cpu().numpy(), rk)
+    np.testing.assert_array_equal(prop.cpu().numpy(), rp)
+    # a tight cluster that forces the scan through all 1,563 column blocks
+    c = 0.5 + rng.normal(0, 0.003, (K, 2))
+    half = 0.2 + rng.normal(0, 0.002, (K, 2))
+    dense = np.concatenate([c - half, c + half], 1).astype(np.float32)[None]
+    prop, keep, cnt = ops.nms(T(dense, dev), 0.7, post_n)
+    rp, rk, rc = O.combined_nms(dense, None, post_n, 0.7)
+    assert rc[0] < post_n
+    np.testing.assert_array_equal(keep.cpu().numpy(), rk)
+    nms_properties(dense[0], keep[0].cpu().numpy(), int(cnt[0]), 0.7, post_n)
+    # idempotence: NMS of the kept boxes keeps every one of them
+    kept = rp[:, : rc[0]]
+    _, keep2, cnt2 = ops.nms(T(kept, dev), 0.7, post_n)
+    assert int(cnt2[0]) == rc[0]
+
+
+def test_config3_assign_and_labels_g200(dev):
+    from objectdetection_amd import ops
+    H, W = 50, 83
+    scales, ratios = (64, 128, 256, 384, 512), (0.5, 1, 2)
+    a = O.make_anchor(H, W, scales, ratios, 1333.0, 800.0)
+    assert a.reshape(-1, 4).shape[0] == 62250
+    d = O.synth_inputs(seed=7, B=1, H=H, W=W, A=15, C=4, G=200, n_gt=200, with_fmap=False)
+    da = ops.anchors(H, W, scales, ratios, 1333.0, 800.0, dev)
+    np.testing.assert_array_equal(da.cpu().numpy(), a)
+    mi, best, flags, _ = ops.iou_assign(da.reshape(-1, 4), T(d["gt"], dev))
+    st = O.rpn_assign(a, d["gt"][0])
+    np.testing.assert_array_equal(best[0].cpu().numpy(), st["best"])
+    np.testing.assert_array_equal(mi[0].cpu().numpy(), st["max_iou"])
+    out = ops.rpn_sample(da, T(d["gt"], dev), best, flags, seed=3)
+    ref = O.patch_batch(dict(image=None, bbox=d["gt"][0], label=d["label"][0]), a, seed=3)
+    np.testing.assert_array_equal(out["pos"][0].cpu().numpy(), ref[5])
+    np.testing.assert_array_equal(out["gt_list"][0].cpu().numpy(), ref[4])
