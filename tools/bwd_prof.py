@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Times frcnn_roi_crop_pool_bwd on the bench workload's proposals."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from objectdetection_amd import ops  # noqa: E402
+from objectdetection_amd.pipeline import RegionProposalPath  # noqa: E402
+
+B = int(os.environ.get("ROI_B", "8"))
+REPS = int(os.environ.get("ROI_REPS", "3"))
+dev = torch.device("cuda:0")
+cfg = bench.workload_cfg()
+fmap, score, coord, gt, label = bench.make_inputs(cfg, B, 512, dev, 1000)
+path = RegionProposalPath(cfg, B, 512, dev, train=False, want_winner=True)
+path.run(fmap, score, coord)
+dY = torch.randn_like(path.pooled)
+torch.cuda.synchronize()
+ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+ts = []
+for _ in range(REPS):
+    ev0.record()
+    g = ops.roi_crop_pool_bwd(dY, path.winner, path.proposed, tuple(fmap.shape), cfg.crop, cfg.pool)
+    ev1.record()
+    torch.cuda.synchronize()
+    ts.append(ev0.elapsed_time(ev1))
+alg = dY.numel() * 4 + path.winner.numel() + g.numel() * 4
+print(f"roi bwd B={B}: min {min(ts):.3f} ms ({min(ts)/B*1e3:.1f} us/image)  "
+      f"{alg/min(ts)/1e6:.1f} GB/s algorithmic")

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Copy the judged summaries of a tools/collect_profiles.sh run from gpurun_out/<tag>/ into
+profiles/ (tracked) and derive profiles/roi_fwd_traffic.json (HBM bytes per launch of the
+dominant kernel: 2 x FETCH_SIZE (gfx950 reports half of a wide coalesced read) + WRITE_SIZE)."""
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, name = sys.argv[1], sys.argv[2]          # e.g. r01a r01
+src = os.path.join(ROOT, "gpurun_out", tag)
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{name}_bench.json"))
+stats = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0]
+shutil.copy(stats, os.path.join(dst, f"{name}_kernel_stats.csv"))
+with open(os.path.join(dst, f"{name}_pmc_roi_fwd.txt"), "w") as out:
+    for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
+        if os.path.isdir(d):
+            out.write(subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"),
+                                      d, "roi_fwd"], capture_output=True, text=True).stdout)
+vals = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob(os.path.join(src, f"pmc_{c}", "*", "*counter_collection.csv"))[0]
+    per = {}
+    for r in csv.DictReader(open(f)):
+        if "roi_fwd" in r["Kernel_Name"] and r["Counter_Name"] == c:
+            per[r["Dispatch_Id"]] = per.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+    vals[c] = sum(per.values()) / len(per)
+bench = json.load(open(os.path.join(src, "bench.json")))
+rec = {
+    "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py workload, {tag}",
+    "batch": bench["config"]["images_per_gpu_per_step"], "channels": 512,
+    "fetch_size_kb": vals["FETCH_SIZE"], "write_size_kb": vals["WRITE_SIZE"],
+    "hbm_bytes_per_launch": 2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024,
+    "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
+}
+json.dump(rec, open(os.path.join(dst, "roi_fwd_traffic.json"), "w"), indent=1)
+print(json.dumps(rec))
