@@ -522,6 +522,135 @@ roi_bwd_cl_kernel(const float* __restrict__ dY, const uint8_t* __restrict__ winn
     }
 }
 
+// ---- backward, fast path: one wave per feature cell, no LDS, no barrier.
+// Lane = RoI while candidates are detected (64 at a time, conservative reach
+// test, ballot), then lane = channel quad while a candidate is applied.  For a
+// candidate the wave evaluates all sample rows (lanes 0-31) and sample columns
+// (lanes 32-63) at once; ballots give the sample rows / columns whose bilinear
+// footprint contains this cell, and the (few) hits are walked by scalar loops.
+// Summation order per cell: RoI ascending, sample (sy,sx) row-major, corner
+// TL,TR,BL,BR.
+__device__ __forceinline__ bool axis_reaches(float c1, float c2, int dim, int n, int target) {
+    float first, last;
+    if (n > 1) {
+        const float scale = ((c2 - c1) * (float)(dim - 1)) / (float)(n - 1);
+        first = c1 * (float)(dim - 1);
+        last = c1 * (float)(dim - 1) + (float)(n - 1) * scale;
+    } else {
+        first = last = (float)(0.5 * (double)(c1 + c2) * (double)(dim - 1));
+    }
+    const float lo = floorf(fminf(first, last)), hi = ceilf(fmaxf(first, last));
+    return (float)target >= lo && (float)target <= hi;      // NaN -> false
+}
+
+template <int POOL, int NQ>
+__global__ void __launch_bounds__(64)
+roi_bwd_wave_kernel(const float* __restrict__ dY, const uint8_t* __restrict__ winner,
+                    const float4* __restrict__ rois, int R, int H, int W, int C, int ch, int cw,
+                    float* __restrict__ dfmap) {
+    const int x = blockIdx.x, y = blockIdx.y, b = blockIdx.z;
+    const int lane = threadIdx.x;
+    const int ph = ch / POOL, pw = cw / POOL;
+    const int C4 = C >> 2;
+    float4 acc[NQ];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4* rb = rois + (size_t)b * R;
+    const bool isx = lane >= 32;
+    const int s = lane & 31;
+    const int target = isx ? x : y;
+    const int ns = isx ? cw : ch, dim = isx ? W : H;
+#pragma unroll 1
+    for (int r0 = 0; r0 < R; r0 += 64) {
+        const int r = r0 + lane;
+        float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
+        bool cand = false;
+        if (r < R) {
+            box = rb[r];
+            cand = axis_reaches(box.x, box.z, H, ch, y) && axis_reaches(box.y, box.w, W, cw, x);
+        }
+        unsigned long long m = __ballot(cand);
+#pragma unroll 1
+        while (m != 0ull) {                                   // wave-uniform
+            const int l = __ffsll((long long)m) - 1;
+            m &= m - 1ull;
+            const float by1 = rlf(box.x, l), bx1 = rlf(box.y, l);
+            const float by2 = rlf(box.z, l), bx2 = rlf(box.w, l);
+            int lo = 0, hi = 0, ok = 0;
+            float fr = 0.f;
+            if (s < ns) axis_sample(isx ? bx1 : by1, isx ? bx2 : by2, dim, ns, s, lo, hi, fr, ok);
+            const bool v = s < ns && ok;
+            const unsigned long long mlo = __ballot(v && lo == target);
+            const unsigned long long mhi = __ballot(v && hi == target);
+            const uint32_t ylo_m = (uint32_t)mlo, yhi_m = (uint32_t)mhi;
+            const uint32_t xlo_m = (uint32_t)(mlo >> 32), xhi_m = (uint32_t)(mhi >> 32);
+            uint32_t ym = ylo_m | yhi_m;
+            const uint32_t xm_all = xlo_m | xhi_m;
+            if (ym == 0u || xm_all == 0u) continue;
+            const size_t rbase = ((size_t)b * R + (r0 + l)) * (size_t)(ph * pw) * C;
+            while (ym != 0u) {
+                const int sy = __ffs((int)ym) - 1;
+                ym &= ym - 1u;
+                const float ly = rlf(fr, sy);
+                const bool top = (ylo_m >> sy) & 1u, bot = (yhi_m >> sy) & 1u;
+                const float wt = 1.0f - ly, wb = ly;
+                uint32_t xm = xm_all;
+                while (xm != 0u) {
+                    const int sx = __ffs((int)xm) - 1;
+                    xm &= xm - 1u;
+                    const float lx = rlf(fr, 32 + sx);
+                    const bool left = (xlo_m >> sx) & 1u, right = (xhi_m >> sx) & 1u;
+                    const float wl = 1.0f - lx, wr = lx;
+                    const uint32_t k = (uint32_t)((sy % POOL) * POOL + (sx % POOL));
+                    const size_t o = rbase + (size_t)((sy / POOL) * pw + (sx / POOL)) * C;
+#pragma unroll
+                    for (int u = 0; u < NQ; ++u) {
+                        const int c4 = lane + 64 * u;
+                        if (c4 >= C4) break;
+                        float4 g = *reinterpret_cast<const float4*>(dY + o + c4 * 4);
+                        if (POOL > 1) {
+                            const uint32_t wv = *reinterpret_cast<const uint32_t*>(winner + o + c4 * 4);
+                            if ((wv & 0xFFu) != k) g.x = 0.f;
+                            if (((wv >> 8) & 0xFFu) != k) g.y = 0.f;
+                            if (((wv >> 16) & 0xFFu) != k) g.z = 0.f;
+                            if ((wv >> 24) != k) g.w = 0.f;
+                        }
+                        // a non-winner channel adds +0 (x + 0 == x): same value as skipping it
+                        if (top) {
+                            const float4 d = make_float4(wt * g.x, wt * g.y, wt * g.z, wt * g.w);
+                            if (left) {
+                                acc[u].x += wl * d.x; acc[u].y += wl * d.y;
+                                acc[u].z += wl * d.z; acc[u].w += wl * d.w;
+                            }
+                            if (right) {
+                                acc[u].x += wr * d.x; acc[u].y += wr * d.y;
+                                acc[u].z += wr * d.z; acc[u].w += wr * d.w;
+                            }
+                        }
+                        if (bot) {
+                            const float4 d = make_float4(wb * g.x, wb * g.y, wb * g.z, wb * g.w);
+                            if (left) {
+                                acc[u].x += wl * d.x; acc[u].y += wl * d.y;
+                                acc[u].z += wl * d.z; acc[u].w += wl * d.w;
+                            }
+                            if (right) {
+                                acc[u].x += wr * d.x; acc[u].y += wr * d.y;
+                                acc[u].z += wr * d.z; acc[u].w += wr * d.w;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    float* dst = dfmap + (((size_t)b * H + y) * W + x) * C;
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+        const int c4 = lane + 64 * u;
+        if (c4 < C4) *reinterpret_cast<float4*>(dst + c4 * 4) = acc[u];
+    }
+}
+
 }  // namespace frcnn
 
 using namespace frcnn;
@@ -601,6 +730,21 @@ extern "C" int frcnn_roi_crop_pool_bwd(const float* dY, const uint8_t* winner, c
     const dim3 grid(W, H, B), block(128);
     const float4* rb = reinterpret_cast<const float4*>(rois);
     hipStream_t st = (hipStream_t)stream;
+    if (crop_h <= 32 && crop_w <= 32) {
+        const int nq = (C / 4 + 63) / 64;                 // channel quads per lane, <= 8
+#define FRCNN_BWD(P, Q)                                                                          \
+    FRCNN_LAUNCH((roi_bwd_wave_kernel<P, Q>), grid, dim3(64), 0, st, dY, winner, rb, R, H, W, C,  \
+                 crop_h, crop_w, dfmap)
+#define FRCNN_BWD_P(P)                                                                           \
+    do {                                                                                         \
+        if (nq <= 1) FRCNN_BWD(P, 1); else if (nq <= 2) FRCNN_BWD(P, 2);                          \
+        else if (nq <= 4) FRCNN_BWD(P, 4); else FRCNN_BWD(P, 8);                                  \
+    } while (0)
+        if (pool == 2) FRCNN_BWD_P(2); else FRCNN_BWD_P(1);
+#undef FRCNN_BWD_P
+#undef FRCNN_BWD
+        return FRCNN_OK;
+    }
     if (pool == 2)
         FRCNN_LAUNCH(roi_bwd_cl_kernel<2>, grid, block, 0, st, dY, winner, rb, R, H, W, C,
                            crop_h, crop_w, dfmap);

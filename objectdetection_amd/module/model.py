@@ -44,3 +44,29 @@ def roi_pool(fmap: torch.Tensor, proposed: torch.Tensor, cfg: PathConfig = REFER
              want_winner: bool = False):
     """crop_and_resize (module/model.py:54) + MaxPool2D (module/model.py:30) in one kernel."""
     return ops.roi_crop_pool_fwd(fmap, proposed, cfg.crop, cfg.pool, want_winner)
+
+
+class _RoICropPool(torch.autograd.Function):
+    """Differentiable fused crop + max-pool.  The reference stops the gradient here
+    (module/model.py:71); this is the exact adjoint w.r.t. the feature map, computed by
+    frcnn_roi_crop_pool_bwd (no atomics, fixed summation order).  Boxes get no gradient."""
+
+    @staticmethod
+    def forward(ctx, fmap, proposed, crop, pool):
+        out, win = ops.roi_crop_pool_fwd(fmap, proposed, crop, pool, want_winner=pool > 1)
+        ctx.save_for_backward(proposed, win if win is not None else proposed.new_empty(0))
+        ctx.meta = (tuple(fmap.shape), crop, pool)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        proposed, win = ctx.saved_tensors
+        shape, crop, pool = ctx.meta
+        g = ops.roi_crop_pool_bwd(grad_out.contiguous(), win if pool > 1 else None, proposed, shape,
+                                  crop, pool)
+        return g, None, None, None
+
+
+def roi_pool_autograd(fmap: torch.Tensor, proposed: torch.Tensor, cfg: PathConfig = REFERENCE):
+    """roi_pool with a backward pass to the feature map (for end-to-end training)."""
+    return _RoICropPool.apply(fmap, proposed, tuple(cfg.crop), int(cfg.pool))

@@ -170,6 +170,31 @@ def test_roi_backward_exact(dev):
     np.testing.assert_array_equal(got.cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("C,pool,crop,R", [(512, 2, (14, 14), 30), (320, 2, (14, 14), 20),
+                                              (64, 1, (6, 6), 25), (2048, 2, (8, 12), 6),
+                                              (12, 2, (14, 14), 10)])
+def test_roi_backward_exact_shapes(dev, C, pool, crop, R):
+    """wave-per-cell kernel with 1/2/8 channel quads per lane, ragged C, plain crop."""
+    from objectdetection_amd import ops
+    rng = np.random.default_rng(C + R)
+    H, W = 10, 13
+    fm = np.maximum(rng.standard_normal((2, H, W, C)).astype(np.float32), 0)
+    y1 = rng.uniform(-0.05, 0.7, (2, R)); x1 = rng.uniform(-0.05, 0.7, (2, R))
+    prop = np.stack([y1, x1, y1 + rng.uniform(0.02, 0.6, (2, R)), x1 + rng.uniform(0.02, 0.6, (2, R))],
+                    -1).astype(np.float32)
+    prop[0, 0] = [0, 0, 1, 1]
+    prop[0, 1] = [0, 0, 0, 0]
+    prop[1, 0] = [0.8, 0.1, 0.1, 0.9]      # flipped
+    prop[1, 1] = [0.2, 0.2, 0.2, 0.7]      # zero height: all sample rows coincide
+    out, win = ops.roi_crop_pool_fwd(T(fm, dev), T(prop, dev), crop, pool, want_winner=pool > 1)
+    ro, ra = O.roi_crop_pool(fm, prop, crop, pool)
+    np.testing.assert_array_equal(out.cpu().numpy(), ro)
+    dY = rng.standard_normal(ro.shape).astype(np.float32)
+    got = ops.roi_crop_pool_bwd(T(dY, dev), win, T(prop, dev), fm.shape, crop, pool)
+    ref = O.roi_crop_pool_bwd(dY, ra, fm.shape, prop, crop, pool)
+    np.testing.assert_array_equal(got.cpu().numpy(), ref)
+
+
 @pytest.mark.parametrize("mode", ["keys", "philox"])
 def test_making_frcnn_input(dev, ref_inputs, mode):
     from objectdetection_amd import ops
@@ -206,3 +231,22 @@ def test_making_frcnn_input(dev, ref_inputs, mode):
     np.testing.assert_allclose(gc.cpu().numpy()[fin], ref_gc[fin], rtol=1e-5, atol=1e-6)
     rc = O.crop_and_resize(d["fmap"], prop[:, :40].reshape(-1, 4), np.repeat(np.arange(2), 40))
     np.testing.assert_array_equal(crop[:, :40].cpu().numpy().reshape(rc.shape), rc)
+
+
+def test_roi_pool_autograd(dev):
+    from objectdetection_amd import ops
+    from objectdetection_amd.module import roi_pool_autograd
+    rng = np.random.default_rng(4)
+    fm = torch.from_numpy(rng.standard_normal((1, 9, 11, 64)).astype(np.float32)).to(dev)
+    fm.requires_grad_(True)
+    y1, x1 = rng.uniform(0, 0.6, 15), rng.uniform(0, 0.6, 15)
+    prop = T(np.stack([y1, x1, y1 + 0.3, x1 + 0.35], 1).astype(np.float32)[None], dev)
+    out = roi_pool_autograd(fm, prop)
+    w = torch.from_numpy(rng.standard_normal(tuple(out.shape)).astype(np.float32)).to(dev)
+    (out * w).sum().backward()
+    _, win = ops.roi_crop_pool_fwd(fm.detach(), prop, (14, 14), 2, want_winner=True)
+    ref = ops.roi_crop_pool_bwd(w, win, prop, tuple(fm.shape), (14, 14), 2)
+    assert torch.equal(fm.grad, ref)
+    # adjoint identity: <w, out(f)> == <grad, f> for the recorded winners
+    lhs, rhs = (out.detach() * w).sum().item(), (fm.grad * fm.detach()).sum().item()
+    assert abs(lhs - rhs) <= 1e-3 * max(1.0, abs(lhs))
