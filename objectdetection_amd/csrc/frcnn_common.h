@@ -219,6 +219,25 @@ __host__ __device__ __forceinline__ int next_pow2(int v) {
     return p;
 }
 
+// ------------------------------------------------------- one-instruction min/max ----
+// fminf()/fmaxf() make hipcc canonicalise each operand first (an extra v_max per
+// operand); these are the bare instructions.  NaN operands are not expected here.
+__device__ __forceinline__ float vmax2(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmin2(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // ------------------------------------------------------------ box arithmetic ----
 // decode of one box, op order of module/data.py:163-175 (clip_wh=false) and
 // :185-196 (clip_wh=true)

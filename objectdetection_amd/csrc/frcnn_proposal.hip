@@ -92,9 +92,9 @@ __device__ __forceinline__ unsigned long long mask_tile(const NBox& a, float c1,
 #pragma unroll 8
     for (int c = 0; c < 64; ++c) {
         const NBox cb = cols[c];
-        const float iy0 = fmaxf(a.y0, cb.y0), ix0 = fmaxf(a.x0, cb.x0);
-        const float iy1 = fminf(a.y1, cb.y1), ix1 = fminf(a.x1, cb.x1);
-        const float inter = fmaxf(iy1 - iy0, 0.0f) * fmaxf(ix1 - ix0, 0.0f);
+        const float iy0 = vmax2(a.y0, cb.y0), ix0 = vmax2(a.x0, cb.x0);
+        const float iy1 = vmin2(a.y1, cb.y1), ix1 = vmin2(a.x1, cb.x1);
+        const float inter = vmax2(iy1 - iy0, 0.0f) * vmax2(ix1 - ix0, 0.0f);
         bool p = inter * c1 > a.t + cb.t;
         if (DIAG) p = p && (c > lane);
         if (__any(p)) {

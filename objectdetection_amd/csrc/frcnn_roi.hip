@@ -192,18 +192,6 @@ __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t rs, uint32_t v
     t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
     __builtin_amdgcn_raw_buffer_store_b128(t, rs, voff, soff, 0);
 }
-// single-instruction maxima (fmaxf() would add a canonicalising v_max per operand)
-__device__ __forceinline__ float vmax2(float a, float b) {
-    float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ float vmax3(float a, float b, float c) {
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
 template <bool B> struct BoolTag { static constexpr bool value = B; };
 
 template <int POOL, bool WIN>

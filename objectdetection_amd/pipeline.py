@@ -11,7 +11,10 @@ synchronisation:
   6. proposal <-> GT labels, targets     (making_frcnn_input, module/data.py:215-259)
   7. proposal sampling                   (making_frcnn_input, module/data.py:266-316)
 
-Stages 1-2 and 6-7 are the training-only part (`train=True`).
+Stages 1-2 and 6-7 are the training-only part (`train=True`).  They do not feed
+stages 3-5, so they are issued on a second HIP stream: 1-2 run beside the top-k / NMS
+chain, 6-7 beside the RoI kernel, and the streams are joined with events before run()
+returns (still no host synchronisation).
 """
 from __future__ import annotations
 
@@ -36,6 +39,8 @@ class RegionProposalPath:
         self.cfg, self.B, self.C = cfg, batch, channels
         self.device = torch.device(device)
         self.train, self.fuse_pool = train, fuse_pool
+        self.side = torch.cuda.Stream(self.device) if train else None
+        self._ev = [torch.cuda.Event() for _ in range(3)] if train else None
         dev, B, N = self.device, batch, cfg.N
         f32, i32, i64, u8 = torch.float32, torch.int32, torch.int64, torch.uint8
         e = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
@@ -90,39 +95,49 @@ class RegionProposalPath:
         gt [B,G,4], label [B,G] i64 (both only when train).  Returns self."""
         cfg, B, N = self.cfg, self.B, self.cfg.N
         self._validate(fmap, score, coord, gt, label)
-        st = torch.cuda.current_stream(self.device).cuda_stream
+        main = torch.cuda.current_stream(self.device)
+        st = main.cuda_stream
         seed &= 0xFFFFFFFFFFFFFFFF
         if self.train:
             G = gt.shape[1]
+            ss = self.side.cuda_stream
+            self._ev[0].record(main)
+            self.side.wait_event(self._ev[0])          # inputs were produced on the main stream
             check("frcnn_iou_assign", lib.frcnn_iou_assign(
                 _p(self.anchor), N, _p(gt), B, G, cfg.rpn_pos_thr, cfg.rpn_neg_thr,
-                _p(self.max_iou), _p(self.best_gt), _p(self.flags), None, st))
+                _p(self.max_iou), _p(self.best_gt), _p(self.flags), None, ss))
             r = self.rpn
             check("frcnn_rpn_sample", lib.frcnn_rpn_sample(
                 _p(self.anchor), cfg.H, cfg.W, cfg.A, _p(gt), B, G, _p(self.best_gt),
                 _p(self.flags), None, None, None, seed, image_base, cfg.rpn_batch, cfg.rpn_max_pos,
                 _p(r["label"]), _p(r["anchor"]), _p(r["gt"]), _p(r["gt_list"]), _p(r["pos"]),
-                _p(r["reg"]), _p(r["counts"]), st))
+                _p(r["reg"]), _p(r["counts"]), ss))
         check("frcnn_topk", lib.frcnn_topk(
             _p(score), B, N, cfg.pre_k, _p(self.anchor), _p(coord), _p(self.top_scores),
             _p(self.top_idx), _p(self.cand), st))
         check("frcnn_nms", lib.frcnn_nms(
             _p(self.cand), B, cfg.pre_k, cfg.nms_thr, cfg.post_n, _p(self.proposed),
             _p(self.keep_pos), _p(self.keep_count), _p(self.nms_ws), self.nms_ws.numel(), st))
+        if self.train:
+            self._ev[1].record(main)
+            self.side.wait_event(self._ev[1])          # proposals ready
+            ss = self.side.cuda_stream
+            check("frcnn_label_proposals", lib.frcnn_label_proposals(
+                _p(self.proposed), _p(gt), _p(label), B, cfg.post_n, gt.shape[1], cfg.fg_thr,
+                cfg.iou_floor, cfg.bg_label, cfg.num_classes, _p(self.p_label), _p(self.gt_mask),
+                _p(self.gt_onehot), _p(self.gt_coord), _p(self.p_best), _p(self.p_iou), ss))
+            check("frcnn_sample_proposals", lib.frcnn_sample_proposals(
+                _p(self.p_label), B, cfg.post_n, cfg.bg_label, None, None, None, seed, image_base,
+                cfg.head_batch, cfg.head_max_pos, _p(self.tindex), _p(self.head_counts), ss))
+            self._ev[2].record(self.side)
         sb, sh, sw, sc = fmap.stride()
         if roi_events is not None:
-            roi_events[0].record()
+            roi_events[0].record(main)
         check("frcnn_roi_crop_pool_fwd", lib.frcnn_roi_crop_pool_fwd(
             _p(fmap), B, cfg.H, cfg.W, self.C, sb, sh, sw, sc, _p(self.proposed), cfg.post_n,
             cfg.crop[0], cfg.crop[1], self.pool, _p(self.pooled), _p(self.winner), st))
         if roi_events is not None:
-            roi_events[1].record()
+            roi_events[1].record(main)
         if self.train:
-            check("frcnn_label_proposals", lib.frcnn_label_proposals(
-                _p(self.proposed), _p(gt), _p(label), B, cfg.post_n, gt.shape[1], cfg.fg_thr,
-                cfg.iou_floor, cfg.bg_label, cfg.num_classes, _p(self.p_label), _p(self.gt_mask),
-                _p(self.gt_onehot), _p(self.gt_coord), _p(self.p_best), _p(self.p_iou), st))
-            check("frcnn_sample_proposals", lib.frcnn_sample_proposals(
-                _p(self.p_label), B, cfg.post_n, cfg.bg_label, None, None, None, seed, image_base,
-                cfg.head_batch, cfg.head_max_pos, _p(self.tindex), _p(self.head_counts), st))
+            main.wait_event(self._ev[2])               # join: everything is ordered on `main` again
         return self
