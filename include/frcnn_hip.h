@@ -186,6 +186,22 @@ int frcnn_sample_proposals(const int64_t* p_label, int B, int R, int bg_label,
                            int batch, int max_pos,
                            int64_t* tindex, int32_t* counts, frcnn_stream_t stream);
 
+/* ---- next row f1: detection post-process ------------------------------------------------------
+ * Replaces Faster_RCNN/model_train.py:745-759 (per image): class argmax, gather of that
+ * class's offsets, generate_coord (module/data.py:179-198), drop background,
+ * tf.image.non_max_suppression_with_scores(coord, score, max_out, iou_threshold) (hard NMS;
+ * equal scores: lower proposal index first), keep score >= score_threshold.
+ * proposed [B,R,4], cls_prob [B,R,num_classes], reg [B,R,num_classes,4].
+ * decoded [B,R,4] and cls_arg [B,R] receive every proposal's box / class; boxes
+ * [B,max_out,4], scores [B,max_out], classes / src [B,max_out] i32 (-1 padded; src =
+ * proposal index), count [B].  R <= 16384, max_out <= 1024. */
+int frcnn_detect_postprocess(const float* proposed, const float* cls_prob, const float* reg,
+                             int B, int R, int num_classes, int bg_label, int max_out,
+                             float iou_threshold, float score_threshold,
+                             float* decoded, int32_t* cls_arg, float* boxes, float* scores,
+                             int32_t* classes, int32_t* src, int32_t* count,
+                             frcnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

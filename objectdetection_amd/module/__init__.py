@@ -3,3 +3,4 @@ and return tuples, on torch-ROCm tensors, computed by the HIP kernels."""
 from .anchor import make_anchor  # noqa: F401
 from .data import patch_batch, inverse_trans, generate_coord, making_frcnn_input  # noqa: F401
 from .model import process_fmap, roi_pool, roi_pool_autograd  # noqa: F401
+from .detect import detect  # noqa: F401

@@ -16,7 +16,7 @@ from ._lib import lib, check
 __all__ = [
     "anchors", "iou_assign", "rpn_sample", "encode", "decode_clip", "topk", "nms",
     "nms_workspace_bytes", "roi_crop_pool_fwd", "roi_crop_pool_bwd", "label_proposals",
-    "sample_proposals",
+    "sample_proposals", "detect_postprocess",
 ]
 
 
@@ -280,3 +280,32 @@ def sample_proposals(p_label: torch.Tensor, bg_label: int = 20, keys=None, seed:
             _ptr(pl), B, R, bg_label, _ptr(kp), _ptr(kn), _ptr(ka), seed & 0xFFFFFFFFFFFFFFFF,
             image_base, batch, max_pos, _ptr(tindex), _ptr(counts), _stream(pl)))
     return tindex, counts
+
+
+def detect_postprocess(proposed: torch.Tensor, cls_prob: torch.Tensor, reg: torch.Tensor,
+                       bg_label: int = 20, max_out: int = 30, iou_threshold: float = 0.7,
+                       score_threshold: float = 0.9):
+    """proposed [B,R,4], cls_prob [B,R,NC], reg [B,R,NC*4] -> dict(boxes [B,max_out,4],
+    scores, classes, src, count, decoded [B,R,4], cls_arg [B,R])."""
+    p = _cont(proposed, "proposed", torch.float32)
+    c = _cont(cls_prob, "cls_prob", torch.float32)
+    B, R, NC = c.shape
+    g = _cont(reg, "reg", torch.float32).reshape(B, R, NC, 4)
+    if tuple(p.shape) != (B, R, 4):
+        raise ValueError("proposed must be [B,R,4]")
+    dev = p.device
+    out = dict(
+        decoded=torch.empty((B, R, 4), dtype=torch.float32, device=dev),
+        cls_arg=torch.empty((B, R), dtype=torch.int32, device=dev),
+        boxes=torch.empty((B, max_out, 4), dtype=torch.float32, device=dev),
+        scores=torch.empty((B, max_out), dtype=torch.float32, device=dev),
+        classes=torch.empty((B, max_out), dtype=torch.int32, device=dev),
+        src=torch.empty((B, max_out), dtype=torch.int32, device=dev),
+        count=torch.empty((B,), dtype=torch.int32, device=dev),
+    )
+    with torch.cuda.device(dev):
+        check("frcnn_detect_postprocess", lib.frcnn_detect_postprocess(
+            _ptr(p), _ptr(c), _ptr(g), B, R, NC, bg_label, max_out, iou_threshold, score_threshold,
+            _ptr(out["decoded"]), _ptr(out["cls_arg"]), _ptr(out["boxes"]), _ptr(out["scores"]),
+            _ptr(out["classes"]), _ptr(out["src"]), _ptr(out["count"]), _stream(p)))
+    return out

@@ -663,3 +663,54 @@ def synth_inputs(seed, B, H, W, A, C, G, n_gt=None, gt_side=(0.05, 0.6), num_cla
         gt[b, :n] = np.clip(box, 0.0, 1.0).astype(F32)
         label[b, :n] = rng.integers(0, num_classes, n)
     return dict(score=score, coord=coord, fmap=fmap, gt=gt, label=label)
+
+
+# --------------------------------------------------------------------------
+# f1  detection post-process            Faster_RCNN/model_train.py:745-759
+# --------------------------------------------------------------------------
+
+def nms_with_scores(boxes, scores, max_out, iou_threshold=0.7):
+    """tf.image.non_max_suppression_with_scores, hard NMS (soft_nms_sigma=0),
+    score_threshold=-inf: candidates by descending score (equal scores: lower index
+    first), greedy IoU > threshold, at most max_out.  Returns (indices, scores)."""
+    boxes = np.asarray(boxes, F32).reshape(-1, 4)
+    scores = np.asarray(scores, F32).reshape(-1)
+    order = np.argsort(-scores, kind="stable")
+    keep = nms_keep(boxes[order], iou_threshold, max_out)
+    sel = order[keep]
+    return sel.astype(np.int32), scores[sel]
+
+
+def detect_postprocess(proposed, cls_prob, reg, bg_label=20, max_out=30, iou_threshold=0.7,
+                       score_threshold=0.9):
+    """model_train.py:745-759 per image: class argmax -> that class's offsets ->
+    generate_coord -> drop background -> NMS with scores (max 30, IoU 0.7) -> keep
+    score >= 0.9.  proposed [B,R,4], cls_prob [B,R,NC], reg [B,R,NC*4].
+    Returns boxes [B,max_out,4], scores [B,max_out], classes [B,max_out] (-1 pad),
+    src [B,max_out] (proposal index, -1 pad), count [B]."""
+    proposed = np.asarray(proposed, F32)
+    cls_prob = np.asarray(cls_prob, F32)
+    B, R, NC = cls_prob.shape
+    reg = np.asarray(reg, F32).reshape(B, R, NC, 4)
+    argindex = cls_prob.argmax(axis=2)
+    offset = np.take_along_axis(reg, argindex[..., None, None], axis=2)[:, :, 0, :]
+    result = generate_coord(proposed, offset)
+    pscore = np.take_along_axis(cls_prob, argindex[..., None], axis=2)[..., 0]
+    boxes = np.zeros((B, max_out, 4), F32)
+    scores = np.zeros((B, max_out), F32)
+    classes = np.full((B, max_out), -1, np.int32)
+    src = np.full((B, max_out), -1, np.int32)
+    count = np.zeros(B, np.int32)
+    for b in range(B):
+        fg = np.nonzero(argindex[b] != bg_label)[0]
+        sel, ssc = nms_with_scores(result[b][fg], pscore[b][fg], max_out, iou_threshold)
+        ok = ssc >= F32(score_threshold)
+        sel, ssc = sel[ok], ssc[ok]
+        n = sel.shape[0]
+        count[b] = n
+        boxes[b, :n] = result[b][fg][sel]
+        scores[b, :n] = ssc
+        classes[b, :n] = argindex[b][fg][sel]
+        src[b, :n] = fg[sel]
+    return dict(boxes=boxes, scores=scores, classes=classes, src=src, count=count, decoded=result,
+                argindex=argindex.astype(np.int32))

@@ -286,3 +286,24 @@ def test_sample_proposals_counts():
     t2 = O.sample_proposals(p, seed=1)
     np.testing.assert_array_equal(t, t2)
     assert not np.array_equal(t, O.sample_proposals(p, seed=2))
+
+
+# ------------------------------------------------ detection post-process (f1)
+def test_detect_postprocess_hand_case():
+    prop = np.array([[[0.1, 0.1, 0.5, 0.5],       # class 3, score .95 -> kept
+                      [0.1, 0.1, 0.5, 0.52],      # class 3, score .93, IoU .95 with #0 -> suppressed
+                      [0.6, 0.6, 0.9, 0.9],       # class 7, score .91 -> kept
+                      [0.0, 0.6, 0.3, 0.9],       # background -> dropped
+                      [0.3, 0.0, 0.6, 0.3]]], F32)  # class 1, score .5 -> kept by NMS, cut by score
+    cls = np.full((1, 5, 21), 0.0, F32)
+    cls[0, 0, 3], cls[0, 1, 3], cls[0, 2, 7], cls[0, 3, 20], cls[0, 4, 1] = .95, .93, .91, .99, .5
+    reg = np.zeros((1, 5, 84), F32)               # zero offsets: decoded box = proposal
+    d = O.detect_postprocess(prop, cls, reg)
+    assert d["count"].tolist() == [2]
+    assert d["src"][0, :2].tolist() == [0, 2] and d["classes"][0, :2].tolist() == [3, 7]
+    np.testing.assert_allclose(d["boxes"][0, :2], prop[0, [0, 2]], atol=1e-7)
+    assert (d["src"][0, 2:] == -1).all()
+    # equal scores: lower index first
+    sel, _ = O.nms_with_scores(np.array([[0, 0, .1, .1], [.5, .5, .6, .6]], F32),
+                               np.array([.7, .7], F32), 5)
+    assert sel.tolist() == [0, 1]
