@@ -127,12 +127,14 @@ int frcnn_topk(const float* scores, int B, int N, int K,
  * Replaces tf.image.combined_non_max_suppression(boxes, scores, post_n, post_n,
  * iou_threshold), Faster_RCNN/module/model.py:51 (= module/data.py:209), one
  * class.  boxes [B,K,4] already in descending-score order (ties: earlier
- * first).  Bitmask kernel (wavefront ballot) + one-wave scan per image.
+ * first).  Bitmask kernel (wavefront ballot) + scan, in chunks of 1024
+ * candidates with per-image early exit.
  * proposed [B,post_n,4] = kept boxes clipped to [0,1], zero padded;
  * keep_pos [B,post_n] i32 = kept positions in 0..K-1, -1 padded (may be NULL);
  * keep_count [B] i32 (may be NULL).
- * workspace: frcnn_nms_workspace_bytes(B,K) bytes, 256-byte aligned. */
-size_t frcnn_nms_workspace_bytes(int B, int K);
+ * workspace: frcnn_nms_workspace_bytes(B,K,post_n) bytes, 256-byte aligned
+ * (about 8 KB x (post_n/64 + 16) + 4 x post_n bytes per image; independent of K). */
+size_t frcnn_nms_workspace_bytes(int B, int K, int post_n);
 int frcnn_nms(const float* boxes, int B, int K, float iou_threshold, int post_n,
               float* proposed, int32_t* keep_pos, int32_t* keep_count,
               void* workspace, size_t workspace_bytes, frcnn_stream_t stream);

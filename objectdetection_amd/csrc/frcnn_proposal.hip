@@ -49,17 +49,24 @@ topk_kernel(const float* __restrict__ scores, int N, int K, int n_pad,
 // inter = max(dy,0)*max(dx,0), iou = inter / (area_i + area_j - inter); box i
 // (higher score) suppresses box j when iou > thr (strict).
 //
-// Layout.  Candidates are cut into blocks of 64 in score order.  maskT[b][ib][j]
-// (u64) holds, for column box j, one bit per row box of row block ib: bit r set
-// <=> box ib*64+r suppresses box j (only rows before j can be set).  The greedy
-// scan of column block jb needs the words of row blocks 0..jb only, and those
-// loads do not depend on the scan state, so they stream.
-//
-// Work is issued in chunks of column blocks: mask kernel for the chunk (all row
-// blocks up to the column block), then scan kernel for the chunk.  An image
-// that has collected post_n boxes raises its `done` flag and every later block
-// of that image returns at once, so the pair tests actually executed are about
-// (last candidate examined)^2 / 2 instead of K^2 / 2.
+// Candidates are walked in score order in chunks of NMS_CW column blocks of 64.
+// A candidate can only be suppressed by a KEPT box, so for each chunk the mask
+// kernel tests the chunk's columns against
+//   (a) the boxes kept so far, 64 per "kept tile" (their list is in keep_idx), and
+//   (b) the chunk's own candidates (upper triangle of the chunk's tiles),
+// one wave per 64x64 tile: lane = row box, the 64 column boxes in LDS, the wave
+// ballot of the suppress predicate = the column's mask word (bit r = row r of
+// the tile suppresses the column).  The scan kernel (one workgroup per image)
+// then walks the chunk's column blocks: a column is dead if any kept-tile word
+// is non-zero or an in-chunk word meets that block's keep bits; the block's own
+// triangle is resolved serially by one wave.  An image that has post_n boxes
+// raises `done` and every later block of it returns at once.
+// Pair tests executed: (kept so far) x (columns examined) + the chunk triangles,
+// instead of K^2/2; mask storage is two small per-image buffers reused by
+// every chunk.
+constexpr int NMS_CW = 16;                      // column blocks per chunk
+constexpr int NMS_COLS = NMS_CW * 64;           // columns per chunk
+
 struct NBox { float y0, x0, y1, x1, area, t; };          // t = thr_lo * area
 
 __device__ __forceinline__ NBox norm_box(float4 v, float thr_lo) {
@@ -79,12 +86,10 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
     return ((unsigned long long)hi << 32) | lo;
 }
 
-// One wave = one 64x64 tile: lane = row box (registers), the 64 column boxes sit
-// in LDS.  Per column: a 3-instruction conservative filter
+// One 64x64 tile.  Per column: a 3-instruction conservative filter
 //     inter*(1+thr) > thr*(1-4e-6)*(area_i+area_j)
 // (implied by iou > thr with a margin far above float rounding), and only when
-// some lane passes it the exact division; the wave ballot of the predicate is
-// the column's mask word.
+// some lane passes it the exact division.
 template <bool DIAG>
 __device__ __forceinline__ unsigned long long mask_tile(const NBox& a, float c1, const NBox* cols,
                                                         float thr, int lane) {
@@ -107,13 +112,23 @@ __device__ __forceinline__ unsigned long long mask_tile(const NBox& a, float c1,
     return mine;
 }
 
+// grid (ceil((KT + NMS_CW)/4), NMS_CW, B), 4 waves: wave = one row tile.
+// maskK [B][KT][NMS_COLS], maskD [B][NMS_CW][NMS_COLS].
 __global__ void __launch_bounds__(256)
-nms_mask_kernel(const float4* __restrict__ boxes, int K, int CB, int jb_begin, float thr, float c1,
-                float thr_lo, const int* __restrict__ done, unsigned long long* __restrict__ maskT) {
+nms_mask_kernel(const float4* __restrict__ boxes, int K, int cb0, int KT, int post_n, float thr,
+                float c1, float thr_lo, const int* __restrict__ done,
+                const int* __restrict__ count_g, const int32_t* __restrict__ keep_idx,
+                unsigned long long* __restrict__ maskK, unsigned long long* __restrict__ maskD) {
     const int b = blockIdx.z;
-    const int jb = jb_begin + blockIdx.y;
-    const int ib0 = blockIdx.x * 4;
-    if (ib0 > jb || done[b]) return;                   // block-uniform
+    const int jbl = blockIdx.y;                         // column block inside the chunk
+    const int jb = cb0 + jbl;
+    if (jb * 64 >= K || done[b]) return;                // block-uniform
+    const int count = count_g[b];                       // boxes kept before this chunk
+    const int nkt = (count + 63) >> 6;
+    const int rt0 = blockIdx.x * 4;
+    // tiles rt0..rt0+3: kept tiles are [0,nkt), in-chunk row blocks are KT + [0,jbl]
+    if (rt0 >= nkt && rt0 + 3 < KT) return;             // only empty kept tiles
+    if (rt0 > KT + jbl) return;                         // only tiles right of the diagonal
     __shared__ NBox s_col[64];
     const float4* bx = boxes + (size_t)b * K;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -122,56 +137,68 @@ nms_mask_kernel(const float4* __restrict__ boxes, int K, int CB, int jb_begin, f
         s_col[threadIdx.x] = norm_box(j < K ? bx[j] : zero4, thr_lo);
     }
     __syncthreads();
-    const int ib = ib0 + wave_id();
-    if (ib > jb) return;                               // wave-uniform
+    const int rt = rt0 + wave_id();
     const int lane = lane_id();
-    const int i = ib * 64 + lane;
-    const NBox a = norm_box(i < K ? bx[i] : zero4, thr_lo);
+    float4 rowbox = zero4;
+    bool diag = false;
+    unsigned long long* dst;
+    if (rt < KT) {
+        if (rt >= nkt) return;                          // wave-uniform
+        const int slot = rt * 64 + lane;
+        if (slot < count) rowbox = bx[keep_idx[(size_t)b * post_n + slot]];
+        dst = maskK + ((size_t)b * KT + rt) * NMS_COLS;
+    } else {
+        const int ibl = rt - KT;
+        if (ibl > jbl) return;                          // wave-uniform
+        const int i = (cb0 + ibl) * 64 + lane;
+        if (i < K) rowbox = bx[i];
+        diag = (ibl == jbl);
+        dst = maskD + ((size_t)b * NMS_CW + ibl) * NMS_COLS;
+    }
+    const NBox a = norm_box(rowbox, thr_lo);
     // a tiny row area could underflow the filter's products: +inf makes the filter pass
     // whenever the boxes intersect, and the exact test decides
     const float c1l = a.area < NMS_TINY_AREA ? __builtin_inff() : c1;
-    const unsigned long long mine = (ib == jb) ? mask_tile<true>(a, c1l, s_col, thr, lane)
-                                               : mask_tile<false>(a, c1l, s_col, thr, lane);
-    maskT[((size_t)b * CB + ib) * ((size_t)CB * 64) + (size_t)jb * 64 + lane] = mine;
+    const unsigned long long mine = diag ? mask_tile<true>(a, c1l, s_col, thr, lane)
+                                         : mask_tile<false>(a, c1l, s_col, thr, lane);
+    dst[jbl * 64 + lane] = mine;
 }
 
 // One workgroup (4 waves) per image walks the chunk's column blocks in order.
-// kept[] (LDS) = keep bits of every block so far.  For block jb the waves split
-// the row blocks 0..jb-1: a column is dead if any (word & kept[ib]) is non-zero;
-// wave 0 then resolves the block's own 64x64 triangle serially and emits.
 __global__ void __launch_bounds__(256)
-nms_scan_kernel(const float4* __restrict__ boxes, const unsigned long long* __restrict__ maskT,
-                int K, int CB, int jb_begin, int jb_end, int post_n,
-                unsigned long long* __restrict__ kept_g, int* __restrict__ count_g,
-                int* __restrict__ done, float4* __restrict__ proposed,
+nms_scan_kernel(const float4* __restrict__ boxes, const unsigned long long* __restrict__ maskK,
+                const unsigned long long* __restrict__ maskD, int K, int cb0, int KT, int post_n,
+                int last_chunk, int* __restrict__ count_g, int* __restrict__ done,
+                int32_t* __restrict__ keep_idx, float4* __restrict__ proposed,
                 int32_t* __restrict__ keep_pos, int32_t* __restrict__ keep_count) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    unsigned long long* kept = reinterpret_cast<unsigned long long*>(smem);     // CB words
-    unsigned long long* deadw = kept + CB;                                      // 4 words
-    int* s_cnt = reinterpret_cast<int*>(deadw + 4);
+    __shared__ unsigned long long keptw[NMS_CW];        // keep bits of this chunk's blocks
+    __shared__ unsigned long long deadw[4];
+    __shared__ int s_cnt;
     const int b = blockIdx.x;
-    if (done[b]) return;                               // block-uniform
+    if (done[b]) return;                                // block-uniform
     const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
     const float4* bx = boxes + (size_t)b * K;
-    const size_t KP = (size_t)CB * 64;
-    const unsigned long long* mk = maskT + (size_t)b * CB * KP;
-    unsigned long long* kg = kept_g + (size_t)b * CB;
+    const unsigned long long* mk = maskK + (size_t)b * KT * NMS_COLS;
+    const unsigned long long* md = maskD + (size_t)b * NMS_CW * NMS_COLS;
     float4* prop = proposed + (size_t)b * post_n;
+    int32_t* kidx = keep_idx + (size_t)b * post_n;
     int32_t* kp = keep_pos ? keep_pos + (size_t)b * post_n : nullptr;
-    for (int w = tid; w < jb_begin; w += 256) kept[w] = kg[w];
-    if (tid == 0) *s_cnt = count_g[b];
+    const int count0 = count_g[b];
+    const int nkt = (count0 + 63) >> 6;
+    if (tid == 0) s_cnt = count0;
     __syncthreads();
-    int jb = jb_begin;
+    const int nblk = min(NMS_CW, (K + 63) / 64 - cb0);
 #pragma unroll 1
-    for (; jb < jb_end; ++jb) {
-        const int count = *s_cnt;
-        if (count >= post_n) break;                    // block-uniform
-        const int j0 = jb * 64;
-        const unsigned long long* col = mk + j0 + lane;
-        const unsigned long long diag = wave == 0 ? col[(size_t)jb * KP] : 0ull;
+    for (int jbl = 0; jbl < nblk; ++jbl) {
+        const int count = s_cnt;
+        if (count >= post_n) break;                     // block-uniform
+        const int j0 = (cb0 + jbl) * 64;
+        const int col = jbl * 64 + lane;
+        const unsigned long long diag = wave == 0 ? md[(size_t)jbl * NMS_COLS + col] : 0ull;
         unsigned long long hit = 0ull;
-#pragma unroll 8
-        for (int ib = wave; ib < jb; ib += 4) hit |= col[(size_t)ib * KP] & kept[ib];
+#pragma unroll 4
+        for (int kt = wave; kt < nkt; kt += 4) hit |= mk[(size_t)kt * NMS_COLS + col];
+        for (int ibl = wave; ibl < jbl; ibl += 4) hit |= md[(size_t)ibl * NMS_COLS + col] & keptw[ibl];
         const unsigned long long dead = __ballot(hit != 0ull);
         if (lane == 0) deadw[wave] = dead;
         __syncthreads();
@@ -181,7 +208,7 @@ nms_scan_kernel(const float4* __restrict__ boxes, const unsigned long long* __re
             unsigned long long alive = uniform64(~(deadw[0] | deadw[1] | deadw[2] | deadw[3]) & vmask);
             unsigned long long keptmask = 0ull;
             int room = post_n - count;
-            while (alive != 0ull && room > 0) {        // wave-uniform
+            while (alive != 0ull && room > 0) {         // wave-uniform
                 const int r = __ffsll((long long)alive) - 1;
                 keptmask |= 1ull << r;
                 --room;
@@ -193,19 +220,18 @@ nms_scan_kernel(const float4* __restrict__ boxes, const unsigned long long* __re
                 float4 v = bx[j0 + lane];
                 v.x = clip01(v.x); v.y = clip01(v.y); v.z = clip01(v.z); v.w = clip01(v.w);
                 prop[slot] = v;
+                kidx[slot] = j0 + lane;
                 if (kp) kp[slot] = j0 + lane;
             }
             if (lane == 0) {
-                kept[jb] = keptmask;
-                *s_cnt = count + __popcll(keptmask);
+                keptw[jbl] = keptmask;
+                s_cnt = count + __popcll(keptmask);
             }
         }
         __syncthreads();
     }
-    // persist the state for the next chunk; finish the image if it is complete
-    for (int w = jb_begin + tid; w < jb; w += 256) kg[w] = kept[w];
-    const int count = *s_cnt;
-    if (count >= post_n || jb_end >= CB) {
+    const int count = s_cnt;
+    if (count >= post_n || last_chunk) {
         // zero padding (tf.image.combined_non_max_suppression pads boxes with 0)
         for (int s = count + tid; s < post_n; s += 256) {
             prop[s] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -245,16 +271,18 @@ extern "C" int frcnn_topk(const float* scores, int B, int N, int K, const float*
     return FRCNN_OK;
 }
 
-// workspace = maskT [B][CB][CB*64] u64 | kept [B][CB] u64 | count [B] i32 | done [B] i32
-static size_t nms_mask_bytes(int B, int K) {
-    const size_t CB = ((size_t)K + 63) / 64;
-    return (size_t)B * CB * CB * 64 * sizeof(unsigned long long);
+// workspace = maskK [B][KT][NMS_COLS] u64 | maskD [B][NMS_CW][NMS_COLS] u64 |
+//             keep_idx [B][post_n] i32 | count [B] i32 | done [B] i32
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+static size_t nms_maskk_bytes(int B, int post_n) {
+    return align256((size_t)B * ((size_t)(post_n + 63) / 64) * NMS_COLS * 8);
 }
+static size_t nms_maskd_bytes(int B) { return align256((size_t)B * NMS_CW * NMS_COLS * 8); }
 
-extern "C" size_t frcnn_nms_workspace_bytes(int B, int K) {
-    if (B <= 0 || K <= 0) return 0;
-    const size_t CB = ((size_t)K + 63) / 64;
-    return nms_mask_bytes(B, K) + (size_t)B * CB * 8 + (size_t)B * 8;
+extern "C" size_t frcnn_nms_workspace_bytes(int B, int K, int post_n) {
+    if (B <= 0 || K <= 0 || post_n <= 0) return 0;
+    return nms_maskk_bytes(B, post_n) + nms_maskd_bytes(B) + align256((size_t)B * post_n * 4) +
+           align256((size_t)B * 8);
 }
 
 extern "C" int frcnn_nms(const float* boxes, int B, int K, float iou_threshold, int post_n,
@@ -262,38 +290,35 @@ extern "C" int frcnn_nms(const float* boxes, int B, int K, float iou_threshold, 
                          size_t workspace_bytes, frcnn_stream_t stream) {
     if (!boxes || !proposed || B <= 0 || K <= 0 || post_n <= 0) return FRCNN_E_BADARG;
     if (!(iou_threshold >= 0.0f)) return FRCNN_E_BADARG;
-    if (!workspace || workspace_bytes < frcnn_nms_workspace_bytes(B, K)) return FRCNN_E_WORKSPACE;
+    if (!workspace || workspace_bytes < frcnn_nms_workspace_bytes(B, K, post_n))
+        return FRCNN_E_WORKSPACE;
     if ((reinterpret_cast<uintptr_t>(workspace) & 7u) != 0) return FRCNN_E_BADARG;
     const int CB = (K + 63) / 64;
-    if (CB > 65535 || B > 65535) return FRCNN_E_UNSUPPORTED;
-    const size_t lds = (size_t)CB * 8 + 4 * 8 + 16;
-    if (lds > 150 * 1024) return FRCNN_E_UNSUPPORTED;
+    const int KT = (post_n + 63) / 64;
+    if (B > 65535 || (KT + NMS_CW + 3) / 4 > 0x7FFFFFFF) return FRCNN_E_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     char* ws = reinterpret_cast<char*>(workspace);
-    unsigned long long* maskT = reinterpret_cast<unsigned long long*>(ws);
-    unsigned long long* kept = reinterpret_cast<unsigned long long*>(ws + nms_mask_bytes(B, K));
-    int* count = reinterpret_cast<int*>(ws + nms_mask_bytes(B, K) + (size_t)B * CB * 8);
+    unsigned long long* maskK = reinterpret_cast<unsigned long long*>(ws);
+    ws += nms_maskk_bytes(B, post_n);
+    unsigned long long* maskD = reinterpret_cast<unsigned long long*>(ws);
+    ws += nms_maskd_bytes(B);
+    int32_t* keep_idx = reinterpret_cast<int32_t*>(ws);
+    ws += align256((size_t)B * post_n * 4);
+    int* count = reinterpret_cast<int*>(ws);
     int* done = count + B;
     if (hipMemsetAsync(count, 0, (size_t)B * 8, st) != hipSuccess) return FRCNN_E_LAUNCH;
-    if (lds > 64 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(nms_scan_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return FRCNN_E_LAUNCH;
     // filter constants: iou > thr  =>  inter*(1+thr) > thr*(1-4e-6)*(area_i+area_j)
     const float c1 = 1.0f + iou_threshold;
     const float thr_lo = iou_threshold * 0.999996f;
-    // chunks of column blocks: 8 x 16, then 32,32,64,64,... (fine early: most images stop early)
-    int jb = 0, width = 16, n = 0;
-    while (jb < CB) {
-        const int je = jb + width < CB ? jb + width : CB;
-        FRCNN_LAUNCH(nms_mask_kernel, dim3((je + 3) / 4, je - jb, B), dim3(256), 0, st,
-                     reinterpret_cast<const float4*>(boxes), K, CB, jb, iou_threshold, c1, thr_lo,
-                     done, maskT);
-        FRCNN_LAUNCH(nms_scan_kernel, dim3(B), dim3(256), lds, st,
-                     reinterpret_cast<const float4*>(boxes), maskT, K, CB, jb, je, post_n, kept,
-                     count, done, reinterpret_cast<float4*>(proposed), keep_pos, keep_count);
-        jb = je;
-        if (++n >= 8 && n % 2 == 0 && width < 4096) width *= 2;
+    for (int cb0 = 0; cb0 < CB; cb0 += NMS_CW) {
+        const int last = cb0 + NMS_CW >= CB;
+        FRCNN_LAUNCH(nms_mask_kernel, dim3((KT + NMS_CW + 3) / 4, NMS_CW, B), dim3(256), 0, st,
+                     reinterpret_cast<const float4*>(boxes), K, cb0, KT, post_n, iou_threshold, c1,
+                     thr_lo, done, count, keep_idx, maskK, maskD);
+        FRCNN_LAUNCH(nms_scan_kernel, dim3(B), dim3(256), 0, st,
+                     reinterpret_cast<const float4*>(boxes), maskK, maskD, K, cb0, KT, post_n, last,
+                     count, done, keep_idx, reinterpret_cast<float4*>(proposed), keep_pos,
+                     keep_count);
     }
     return FRCNN_OK;
 }

@@ -173,8 +173,8 @@ def topk(scores: torch.Tensor, k: int, anchor_flat: Optional[torch.Tensor] = Non
     return vals, idx, cand
 
 
-def nms_workspace_bytes(B: int, K: int) -> int:
-    return int(lib.frcnn_nms_workspace_bytes(B, K))
+def nms_workspace_bytes(B: int, K: int, post_n: int) -> int:
+    return int(lib.frcnn_nms_workspace_bytes(B, K, post_n))
 
 
 def nms(boxes: torch.Tensor, iou_threshold: float, post_n: int,
@@ -184,7 +184,7 @@ def nms(boxes: torch.Tensor, iou_threshold: float, post_n: int,
     if b.dim() != 3 or b.shape[-1] != 4:
         raise ValueError("boxes must be [B,K,4]")
     B, K = b.shape[0], b.shape[1]
-    need = nms_workspace_bytes(B, K)
+    need = nms_workspace_bytes(B, K, post_n)
     if workspace is None:
         workspace = torch.empty(need, dtype=torch.uint8, device=b.device)
     proposed = torch.empty((B, post_n, 4), dtype=torch.float32, device=b.device)

@@ -50,7 +50,7 @@ class RegionProposalPath:
         K, R = cfg.pre_k, cfg.post_n
         self.top_scores, self.top_idx = e((B, K), f32), e((B, K), i32)
         self.cand = e((B, K, 4), f32)
-        self.nms_ws = e((ops.nms_workspace_bytes(B, K),), u8)
+        self.nms_ws = e((ops.nms_workspace_bytes(B, K, R),), u8)
         self.proposed, self.keep_pos = e((B, R, 4), f32), e((B, R), i32)
         self.keep_count = e((B,), i32)
         self.pooled = e((B, R, ph, pw, channels), f32)

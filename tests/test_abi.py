@@ -35,8 +35,12 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     """Argument checks run before any launch, so they can be exercised here."""
     from objectdetection_amd import _lib
     L = _lib.lib
-    assert L.frcnn_nms_workspace_bytes(2, 6000) == 2 * 94 * 94 * 64 * 8 + 2 * 94 * 8 + 2 * 8
-    assert L.frcnn_nms_workspace_bytes(0, 10) == 0
+    kt = (1500 + 63) // 64
+    up = lambda v: (v + 255) // 256 * 256
+    assert L.frcnn_nms_workspace_bytes(2, 6000, 1500) == (2 * kt * 1024 * 8 + 2 * 16 * 1024 * 8
+                                                          + up(2 * 1500 * 4) + up(2 * 8))
+    assert L.frcnn_nms_workspace_bytes(2, 100000, 1500) == L.frcnn_nms_workspace_bytes(2, 6000, 1500)
+    assert L.frcnn_nms_workspace_bytes(0, 10, 5) == 0
     assert L.frcnn_topk(None, 1, 10, 5, None, None, None, None, None, None) == _lib.E_BADARG
     one = ctypes.c_void_p(16)        # never dereferenced: the size checks fail first
     assert L.frcnn_topk(one, 1, 10, 11, None, None, one, one, None, None) == _lib.E_BADARG
