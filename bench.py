@@ -201,7 +201,7 @@ def main():
                 "mean_kept_proposals": kept,
             },
             "roofline": {
-                "kernel": "roi_fwd_walk_kernel<2,false>",
+                "kernel": "roi_fwd_stage_kernel<2,false>",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfrcnn_hip.so")
+# FRCNN_HIP_LIB selects another build of the same library (kernel experiments)
+LIB_PATH = os.environ.get("FRCNN_HIP_LIB") or os.path.join(_HERE, "lib", "libfrcnn_hip.so")
 
 OK = 0
 E_BADARG, E_WORKSPACE, E_LAUNCH, E_UNSUPPORTED = -1, -2, -3, -4

@@ -112,23 +112,19 @@ roi_fwd_cl_kernel(const float* __restrict__ fmap, int H, int W, int C, long long
     }
 }
 
-// ---- channels-last "row walker" (C % 64 == 0, crop <= 16x16).
-// Workgroup = one RoI x one 64-channel slice (slice = blockIdx.x % nslice: with
-// 8 slices the blocks dispatched together cover one RoI and each XCD keeps
-// seeing the same eighth of the feature map); thread = (channel quad, pooled
-// column q); no LDS, no barrier: every wave is self-contained.
+// ---- channels-last "staged row walker" (C % 64 == 0, crop <= 16x16): shared pieces.
+// One wave = one RoI x a few 64-channel slices; thread = (channel quad, pooled column);
+// no barrier: every wave is self-contained.
 //
-// The sample rows of a box touch an ascending list of distinct feature rows.
-// Each thread walks that list once: per feature row it loads the four cells
-// its POOL sample columns need (the next row already in flight), lerps them
-// horizontally, and keeps the last two lerped rows in registers; every sample
-// row whose bottom row has arrived is then finished with one vertical lerp per
-// sample column and folded into the running max of its pool window.  A
-// feature row shared by several sample rows (small boxes) is fetched once.
+// The sample rows of a box touch an ascending list of feature rows.  A wave walks that
+// list once: per feature row it brings the cells its sample columns need, lerps them
+// horizontally, keeps the last two lerped rows in registers; every sample row whose
+// bottom row has arrived is then finished with one vertical lerp per sample column and
+// folded into the running max of its pool window.  A feature row shared by several sample
+// rows (small boxes) is fetched once.
 //
-// The row list and the per-sample-row (top, bottom, weight) live one entry per
-// lane and are read with v_readlane by the uniform loop counters, so the loop
-// control runs on the scalar unit.
+// The row list and the per-sample-row entries live one entry per lane and are read with
+// v_readlane by the uniform loop counters, so the loop control runs on the scalar unit.
 constexpr int RW_CS = 64;
 constexpr int RW_LANES = RW_CS / 4;
 constexpr int RW_MAXCROP = 16;
@@ -186,184 +182,662 @@ __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rs, uint32_t 
     const f32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
     return make_float4(v.x, v.y, v.z, v.w);
 }
+// 16-byte buffer store with a scalar row offset.  The store keeps reading its data registers
+// for a few cycles after issue and hipcc (ROCm 7.2) schedules no wait state before a following
+// instruction that overwrites them when the offset is a scalar register: observed on gfx950 as
+// the y component of lanes 12-15 of each 16-lane row taking the NEXT value.  The s_nop keeps
+// the registers stable; the store is issued from asm so that nothing can be placed in between.
 __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff,
                                            float4 v) {
     f32x4 t;
     t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
-    __builtin_amdgcn_raw_buffer_store_b128(t, rs, voff, soff, 0);
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 3"
+                 :: "v"(t), "v"(voff), "s"(rs), "s"(soff) : "memory");
 }
 template <bool B> struct BoolTag { static constexpr bool value = B; };
+template <int I> struct IntTag { static constexpr int value = I; };
 
-template <int POOL, bool WIN>
-__global__ void __launch_bounds__(256)
-roi_fwd_walk_kernel(const float* __restrict__ fmap, int H, int W, int C, long long sb, long long sh,
-                    long long sw, const float4* __restrict__ rois, int R, int ch, int cw,
-                    int nslice, int nsub, float* __restrict__ out, uint8_t* __restrict__ winner) {
-    const int tid = threadIdx.x;
-    const int slice = blockIdx.x % nslice, r = blockIdx.x / nslice, b = blockIdx.y;
-    const float4 box = rois[(size_t)b * R + r];
-    const RowWalk rw = build_row_walk(box.x, box.z, H, ch);
-    const int ph = ch / POOL, pw = cw / POOL;
-    const int cq = tid & (RW_LANES - 1), q = tid / RW_LANES;
-    // this thread's sample columns: byte offsets inside a feature row (32-bit)
-    uint32_t xlo[POOL], xhi[POOL];
-    float xfr[POOL];
-    bool xok[POOL];
-    bool xall = true;
-    const uint32_t chan_off = (uint32_t)(slice * nsub * RW_CS + cq * 4) * 4u;
-#pragma unroll
-    for (int k = 0; k < POOL; ++k) {
-        int lo = 0, hi = 0, ok = 0;
-        float fr = 0.f;
-        const int sx = q * POOL + k;
-        if (sx < cw) axis_sample(box.y, box.w, W, cw, sx, lo, hi, fr, ok);
-        xlo[k] = (uint32_t)lo * (uint32_t)sw * 4u + chan_off;
-        xhi[k] = (uint32_t)hi * (uint32_t)sw * 4u + chan_off;
-        xfr[k] = fr;
-        xok[k] = sx < cw && ok;
-        xall = xall && (xok[k] || sx >= cw);
-    }
-    const bool wave_xall = __all(xall);                   // no extrapolated column in this wave
-    if (q >= pw) return;
-    // uniform descriptors: this image's feature map; this RoI's output block
-    const uint32_t row_bytes = (uint32_t)sh * 4u;
-    const __amdgpu_buffer_rsrc_t img = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(fmap) + (size_t)b * sb, 0, (uint32_t)H * row_bytes, 0x00020000);
-    const size_t oroi = ((size_t)b * R + r) * (size_t)(ph * pw) * C;
-    const uint32_t orow_bytes = (uint32_t)pw * (uint32_t)C * 4u;
-    const __amdgpu_buffer_rsrc_t obuf = __builtin_amdgcn_make_buffer_rsrc(
-        out + oroi, 0, (uint32_t)ph * orow_bytes, 0x00020000);
-    const uint32_t ooff = (uint32_t)q * (uint32_t)C * 4u + chan_off;                   // per thread
-    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int nsy = ph * POOL;
-    float4 best = zero;
-    uchar4 arg = make_uchar4(0, 0, 0, 0);
-    uint32_t sub_off = 0;                 // byte offset of the 64-channel sub-slice in progress
+// ---- the staging.
+// A 16-byte vector load costs the texture path about 20 cycles per wave instruction
+// whatever its lanes fetch (masked-off lanes are not cheaper), an LDS read of the same
+// width about 5.  So a wave stages the DISTINCT cells that its sample columns touch in a
+// feature row -- at most 16 cells, four per direct-to-LDS load (buffer_load ... lds: lane l
+// brings channel quad l%16 of cell l/16, the wave's 1 KiB lands contiguously) -- into a
+// private ring of row slots, one row ahead, and the threads read their cells from there.
+// A slot is read only by the wave that filled it, behind a counted vmcnt wait.  Pooled
+// columns are taken four at a time (one per 16-lane group); two such groups are walked
+// together (two pooled columns per thread) when their cells fit a slot, which halves the
+// scalar work per output.  Boxes with a sample outside the image take a general walk
+// (zero rows / columns), flipped boxes a direct one; everything else the fast walk.
+constexpr int ST_CELLS = 16;
+constexpr int ST_SLOT_BYTES = ST_CELLS * RW_CS * 4;       // 4 KiB
+#ifndef FRCNN_ST_NSLOT
+#define FRCNN_ST_NSLOT 2         // row slots of the fast walk's ring (rows in flight + 1)
+#endif
+constexpr int ST_NSLOT = FRCNN_ST_NSLOT;
+#ifndef FRCNN_ST_PAIR
+#define FRCNN_ST_PAIR 1          // walk two groups of pooled columns together when they fit
+#endif
+#ifndef FRCNN_ST_NSUB
+#define FRCNN_ST_NSUB 2          // consecutive 64-channel slices walked by one wave
+#endif
+#ifndef FRCNN_ST_WPE
+#define FRCNN_ST_WPE 4           // waves per SIMD the staged kernel is compiled for
+#endif
 
-    auto fold = [&](int sy, const float4 (&v)[POOL]) {
-        const int ky = sy % POOL;
-        if (WIN) {
-#pragma unroll
-            for (int kx = 0; kx < POOL; ++kx) {
-                const int k = ky * POOL + kx;
-                if (k == 0) {
-                    best = v[kx];
-                    arg = make_uchar4(0, 0, 0, 0);
-                } else {
-                    if (v[kx].x > best.x) { best.x = v[kx].x; arg.x = k; }
-                    if (v[kx].y > best.y) { best.y = v[kx].y; arg.y = k; }
-                    if (v[kx].z > best.z) { best.z = v[kx].z; arg.z = k; }
-                    if (v[kx].w > best.w) { best.w = v[kx].w; arg.w = k; }
-                }
-            }
-        } else if (POOL == 1) {
-            best = v[0];
-        } else if (ky == 0) {
-            best.x = vmax2(v[0].x, v[POOL - 1].x); best.y = vmax2(v[0].y, v[POOL - 1].y);
-            best.z = vmax2(v[0].z, v[POOL - 1].z); best.w = vmax2(v[0].w, v[POOL - 1].w);
+// distinct values of the (floor, ceil) indices of samples s0 .. s0+ns-1 of one axis
+// (ns <= 32): lane k: position of sample s0+k's floor / ceil in the list (-1:
+// extrapolated); lane u: the list's u-th value; count.  Ascending coordinates only.
+struct AxisUnique { int t_lo, t_hi, t_val, n; float t_fr; };
+
+__device__ __forceinline__ AxisUnique axis_unique(float c1, float c2, int dim, int n, int s0, int ns) {
+    const int lane = lane_id();
+    const int k = lane >> 1, which = lane & 1;
+    int lo = 0, hi = 0, ok = 0;
+    float fr = 0.f;
+    const bool in_range = k < ns && s0 + k < n;
+    if (in_range) axis_sample(c1, c2, dim, n, s0 + k, lo, hi, fr, ok);
+    const bool valid = in_range && ok;
+    const int v = valid ? (which ? hi : lo) : -1 - lane;
+    const int v1 = __shfl_up(v, 1), v2 = __shfl_up(v, 2);
+    const bool is_first = valid && (lane < 1 || v != v1) && (lane < 2 || v != v2);
+    const unsigned long long fm = __ballot(is_first);
+    const unsigned long long le = fm & (lanemask_lt() | (1ull << lane));
+    const int cnt = __popcll(le);
+    const int F = le ? 63 - __clzll((long long)le) : 0;
+    const int vF = __shfl(v, F);
+    const int idx = (v == vF) ? cnt - 1 : cnt - 2;
+    const int src = (2 * lane) & 63;
+    const int s_ok = __shfl((int)valid, src);
+    AxisUnique u;
+    u.t_lo = __shfl(idx, src);
+    u.t_hi = __shfl(idx, src | 1);
+    u.t_fr = __shfl(fr, src);
+    if (!(lane < ns && s_ok)) { u.t_lo = -1; u.t_hi = -1; }
+    u.t_val = __builtin_amdgcn_ds_permute((is_first ? cnt - 1 : 63) << 2, v);
+    u.n = __popcll(fm);
+    return u;
+}
+
+// wait until at most n (uniform) of this wave's vector memory operations are outstanding;
+// n above 8 waits as for 8
+__device__ __forceinline__ void wait_vm_at_most(int n) {
+    if (n < 4) {
+        if (n < 2) {
+            if (n == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else        asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         } else {
-            best.x = vmax3(best.x, v[0].x, v[POOL - 1].x); best.y = vmax3(best.y, v[0].y, v[POOL - 1].y);
-            best.z = vmax3(best.z, v[0].z, v[POOL - 1].z); best.w = vmax3(best.w, v[0].w, v[POOL - 1].w);
+            if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        }
+    } else if (n < 6) {
+        if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    } else {
+        if (n == 6)      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (n == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        else             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    }
+}
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// np (1..4, uniform) direct-to-LDS loads: piece p's lane l brings the 16 bytes at
+// (rsrc base + voff_p + soff) to LDS byte lds_addr + 1024 p + 16 l.  Issued from asm so that
+// the compiler neither counts them nor orders LDS reads behind them: the caller waits with
+// wait_vm_at_most() before it reads the slot.
+__device__ __forceinline__ void lds_dma_pieces(i32x4 rsrc, uint32_t v0, uint32_t v1, uint32_t v2,
+                                               uint32_t v3, uint32_t soff, uint32_t lds_addr, int np) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %7\n\t"
+        "s_cmp_lt_u32 %8, 2\n\t"
+        "buffer_load_dwordx4 %1, %5, %6 offen lds\n\t"
+        "s_cbranch_scc1 1f\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_cmp_lt_u32 %8, 3\n\t"
+        "buffer_load_dwordx4 %2, %5, %6 offen lds\n\t"
+        "s_cbranch_scc1 1f\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_cmp_lt_u32 %8, 4\n\t"
+        "buffer_load_dwordx4 %3, %5, %6 offen lds\n\t"
+        "s_cbranch_scc1 1f\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %4, %5, %6 offen lds\n"
+        "1:\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(rsrc), "s"(soff), "s"(lds_addr), "s"(np)
+        : "memory", "scc");
+}
+
+struct StageCtx {
+    RowWalk rw;
+    float4 box;
+    int W, C, cw, ph, pw, nsy, nsub;
+    uint32_t row_bytes, sw_bytes, chan_off, orow_bytes, ring_addr;
+    i32x4 img_dma;
+    __amdgpu_buffer_rsrc_t obuf;
+    unsigned char* ring;
+    uint8_t* winner_roi;       // winner + this RoI's base, or nullptr
+};
+
+// Walks the rows for NQ groups of four pooled columns starting at group g0; this thread's
+// pooled columns are (g0+t)*4 + lane/16, t < NQ.  ux covers the groups' sample columns.
+template <int POOL, bool WIN, int NQ>
+__device__ __forceinline__ void staged_walk(const StageCtx& c, const AxisUnique& ux, int g0) {
+    const int lane = lane_id();
+    const int cq = lane & (RW_LANES - 1), ql = lane / RW_LANES;
+    constexpr int NS = NQ * POOL;                  // sample columns per thread
+    uint32_t xlo[NS], xhi[NS];
+    float xfr[NS];
+    bool xok[NS];
+    bool xall = true;
+    bool q_live[NQ];
+    uint32_t ooff[NQ];
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) {
+        const int q = (g0 + t) * 4 + ql;
+        q_live[t] = q < c.pw;
+        ooff[t] = (uint32_t)q * (uint32_t)c.C * 4u + c.chan_off;
+#pragma unroll
+        for (int k = 0; k < POOL; ++k) {
+            int lo = 0, hi = 0, ok = 0;
+            float fr = 0.f;
+            const int sx = q * POOL + k;
+            if (sx < c.cw) axis_sample(c.box.y, c.box.w, c.W, c.cw, sx, lo, hi, fr, ok);
+            const int e = t * POOL + k;
+            xfr[e] = fr;
+            xok[e] = sx < c.cw && ok;
+            xall = xall && (xok[e] || sx >= c.cw);
+            const int tl = (t * 4 + ql) * POOL + k;          // sample's place in ux's tables
+            const int li = __shfl(ux.t_lo, tl), ri = __shfl(ux.t_hi, tl);
+            xlo[e] = (uint32_t)max(li, 0) * (RW_CS * 4u) + (uint32_t)cq * 16u;
+            xhi[e] = (uint32_t)max(ri, 0) * (RW_CS * 4u) + (uint32_t)cq * 16u;
+        }
+    }
+    const bool wave_xall = __all(xall);
+    const int ncell = ux.n;                                               // uniform, <= ST_CELLS
+    const int npiece = (ncell + 3) >> 2;
+    uint32_t voff[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int u = min(4 * p + ql, max(ncell - 1, 0));
+        voff[p] = (uint32_t)__shfl(ux.t_val, u) * c.sw_bytes + c.chan_off;
+    }
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const RowWalk& rw = c.rw;
+    const int NR = rw.nr, nsy = c.nsy;
+    float4 best[NQ];
+    uchar4 arg[NQ];
+    float4 hA[NS], hB[NS];
+#pragma unroll
+    for (int e = 0; e < NS; ++e) hA[e] = hB[e] = zero;
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) { best[t] = zero; arg[t] = make_uchar4(0, 0, 0, 0); }
+    unsigned sy = 0;
+    int nst = 0;                 // vector memory operations issued after the staged row in flight
+
+    auto fold = [&](unsigned s, const float4 (&v)[NS]) {
+        const unsigned ky = s % POOL;
+#pragma unroll
+        for (int t = 0; t < NQ; ++t) {
+            const float4* w = &v[t * POOL];
+            if (WIN) {
+#pragma unroll
+                for (int kx = 0; kx < POOL; ++kx) {
+                    const int k = ky * POOL + kx;
+                    if (k == 0) {
+                        best[t] = w[kx];
+                        arg[t] = make_uchar4(0, 0, 0, 0);
+                    } else {
+                        if (w[kx].x > best[t].x) { best[t].x = w[kx].x; arg[t].x = k; }
+                        if (w[kx].y > best[t].y) { best[t].y = w[kx].y; arg[t].y = k; }
+                        if (w[kx].z > best[t].z) { best[t].z = w[kx].z; arg[t].z = k; }
+                        if (w[kx].w > best[t].w) { best[t].w = w[kx].w; arg[t].w = k; }
+                    }
+                }
+            } else if (POOL == 1) {
+                best[t] = w[0];
+            } else if (ky == 0) {
+                best[t].x = vmax2(w[0].x, w[POOL - 1].x); best[t].y = vmax2(w[0].y, w[POOL - 1].y);
+                best[t].z = vmax2(w[0].z, w[POOL - 1].z); best[t].w = vmax2(w[0].w, w[POOL - 1].w);
+            } else {
+                best[t].x = vmax3(best[t].x, w[0].x, w[POOL - 1].x);
+                best[t].y = vmax3(best[t].y, w[0].y, w[POOL - 1].y);
+                best[t].z = vmax3(best[t].z, w[0].z, w[POOL - 1].z);
+                best[t].w = vmax3(best[t].w, w[0].w, w[POOL - 1].w);
+            }
         }
         if (ky == POOL - 1) {
-            const uint32_t orow = (uint32_t)(sy / POOL) * orow_bytes + sub_off;        // uniform
-            buf_store4(obuf, ooff, orow, best);
-            if (WIN)
-                *reinterpret_cast<uchar4*>(winner + oroi + ((orow + ooff) >> 2)) = arg;
+            const uint32_t orow = (s / POOL) * c.orow_bytes;                           // uniform
+            nst = __builtin_amdgcn_readfirstlane(nst + NQ * (WIN ? 2 : 1));
+#pragma unroll
+            for (int t = 0; t < NQ; ++t) {
+                if (q_live[t]) {
+                    buf_store4(c.obuf, ooff[t], orow, best[t]);
+                    if (WIN)
+                        *reinterpret_cast<uchar4*>(c.winner_roi + ((orow + ooff[t]) >> 2)) = arg[t];
+                }
+            }
         }
     };
-
-    if (!rw.walk) {
-        // flipped box: rows are not ascending; fetch every corner directly
-        for (int sub = 0; sub < nsub; ++sub, sub_off += RW_CS * 4)
-        for (int sy = 0; sy < nsy; ++sy) {
-            const int lo = rl(rw.t_lo, sy), hi = rl(rw.t_hi, sy);
+    auto stage_row = [&](int j, int slot) {
+        if (npiece > 0) {
+            const uint32_t roff = (uint32_t)rl(rw.t_row, j) * c.row_bytes;             // uniform
+            lds_dma_pieces(c.img_dma, voff[0], voff[1], voff[2], voff[3], roff,
+                           c.ring_addr + (uint32_t)slot * ST_SLOT_BYTES, npiece);
+        }
+        nst = 0;
+    };
+    // finish every sample row that needs nothing beyond unique row j
+    auto drain = [&](int j, const float4 (&hc)[NS], const float4 (&hp)[NS], auto xtag) {
+        constexpr bool XALL = decltype(xtag)::value;
+        while (sy < (unsigned)nsy) {
+            const int hi = rl(rw.t_hi, sy);               // -1: extrapolated row
+            if (hi > j) break;
+            const int lo = rl(rw.t_lo, sy);
             const float fr = rlf(rw.t_fr, sy);
-            float4 v[POOL];
+            float4 v[NS];
+            if (lo < 0) {
 #pragma unroll
-            for (int k = 0; k < POOL; ++k) {
-                v[k] = zero;
-                if (lo >= 0 && xok[k]) {
-                    const uint32_t rt = (uint32_t)lo * row_bytes + sub_off, rb = (uint32_t)hi * row_bytes + sub_off;
-                    const float4 top = lerp4(buf_load4(img, xlo[k], rt), buf_load4(img, xhi[k], rt),
-                                             xfr[k]);
-                    const float4 bot = lerp4(buf_load4(img, xlo[k], rb), buf_load4(img, xhi[k], rb),
-                                             xfr[k]);
-                    v[k] = lerp4(top, bot, fr);
+                for (int e = 0; e < NS; ++e) v[e] = zero;
+            } else if (lo == j) {
+#pragma unroll
+                for (int e = 0; e < NS; ++e) {
+                    v[e] = lerp4(hc[e], hc[e], fr);
+                    if (!XALL && !xok[e]) v[e] = zero;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < NS; ++e) {
+                    v[e] = lerp4(hp[e], hc[e], fr);
+                    if (!XALL && !xok[e]) v[e] = zero;
                 }
             }
             fold(sy, v);
+            ++sy;
+        }
+    };
+    auto step = [&](int j, int slot, float4 (&hc)[NS], const float4 (&hp)[NS], auto xtag) {
+        wait_vm_at_most(nst);                              // row j has landed in its slot
+        const unsigned char* sp = c.ring + slot * ST_SLOT_BYTES;
+        float4 cl[NS], cr[NS];
+#pragma unroll
+        for (int e = 0; e < NS; ++e) {
+            cl[e] = *reinterpret_cast<const float4*>(sp + xlo[e]);
+            cr[e] = *reinterpret_cast<const float4*>(sp + xhi[e]);
+        }
+        asm volatile("" ::: "memory");
+        if (j + 1 < NR) stage_row(j + 1, slot ^ 1);        // the slot read one step ago
+#pragma unroll
+        for (int e = 0; e < NS; ++e) hc[e] = lerp4(cl[e], cr[e], xfr[e]);
+        drain(j, hc, hp, xtag);
+    };
+    auto run = [&](auto xtag) {
+        drain(-1, hA, hB, xtag);                           // leading extrapolated sample rows
+        if (NR > 0) stage_row(0, 0);
+#pragma unroll 1
+        for (int j = 0; j < NR; j += 2) {
+            step(j, 0, hA, hB, xtag);
+            if (j + 1 < NR) step(j + 1, 1, hB, hA, xtag);
+        }
+        drain(NR, hA, hB, xtag);                           // trailing extrapolated sample rows
+    };
+#pragma unroll 1
+    for (int sub = 0; sub < c.nsub; ++sub) {
+        if (wave_xall) run(BoolTag<true>{}); else run(BoolTag<false>{});
+#pragma unroll
+        for (int p = 0; p < 4; ++p) voff[p] += RW_CS * 4;
+#pragma unroll
+        for (int t = 0; t < NQ; ++t) ooff[t] += RW_CS * 4;
+        sy = 0;
+    }
+}
+
+// The row list of the fast walk: every sample row's (floor, ceil) rows sit at CONSECUTIVE
+// places p, p+1 of the list, so a sample row is always "previous lerped row, current lerped
+// row".  A sample that falls exactly on a feature row lists that row twice (the walk then
+// visits it twice and forms top + (bottom - top) * w from two equal rows, as the definition
+// does).  lane s: place of sample row s's ceil row and its weight; lane j: feature row at
+// place j; nr places.  Only meaningful when every sample row is inside the image.
+struct RowDup { int t_hi, t_row, nr; float t_fr; bool all_valid; };
+
+__device__ __forceinline__ RowDup build_row_dup(float y1, float y2, int H, int ch) {
+    const int lane = lane_id();
+    const int s = lane >> 1, which = lane & 1;
+    int lo = 0, hi = 0, ok = 0;
+    float fr = 0.f;
+    if (s < ch) axis_sample(y1, y2, H, ch, s, lo, hi, fr, ok);
+    const bool in_list = s < ch;
+    const int plo = __shfl_up(lo, 2), phi = __shfl_up(hi, 2);
+    const bool pair_eq = s > 0 && lo == plo && hi == phi;
+    const bool shift = s > 0 && !pair_eq && lo == phi;
+    const bool is_first = in_list && (which ? !pair_eq : !(pair_eq || shift));
+    const unsigned long long fm = __ballot(is_first);
+    const int cnt = __popcll(fm & (lanemask_lt() | (1ull << lane)));
+    const int idx = is_first ? cnt - 1 : ((which == 0 && pair_eq) ? cnt - 2 : cnt - 1);
+    RowDup d;
+    d.all_valid = __all(!in_list || ok) && !(y2 < y1);
+    d.t_hi = __shfl(idx, (2 * lane + 1) & 63);
+    d.t_fr = __shfl(fr, (2 * lane) & 63);
+    if (lane >= ch) d.t_hi = -1;
+    d.t_row = __builtin_amdgcn_ds_permute((is_first ? cnt - 1 : 63) << 2, which ? hi : lo);
+    d.nr = __popcll(fm);
+    return d;
+}
+
+// Four channels as two float pairs: arithmetic on a pair is one packed instruction
+// (v_pk_add_f32 / v_pk_mul_f32), the same issue cost as the scalar form for twice the work.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct Quad { f32x2 a, b; };
+
+__device__ __forceinline__ Quad quad_lerp(Quad p, Quad q, float w) {
+    const f32x2 w2 = {w, w};
+    Quad r;
+    r.a = p.a + (q.a - p.a) * w2;
+    r.b = p.b + (q.b - p.b) * w2;
+    return r;
+}
+__device__ __forceinline__ Quad quad_load_lds(const unsigned char* p) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+    Quad r;
+    r.a = __builtin_shufflevector(t, t, 0, 1);
+    r.b = __builtin_shufflevector(t, t, 2, 3);
+    return r;
+}
+
+// Fast walk: every sample row and every sample column of these groups lies inside the image.
+template <int POOL, bool WIN, int NQ>
+__device__ __forceinline__ void staged_walk_hot(const StageCtx& c, const RowDup& rd,
+                                                const AxisUnique& ux, int g0) {
+    const int lane = lane_id();
+    const int cq = lane & (RW_LANES - 1), ql = lane / RW_LANES;
+    constexpr int NS = NQ * POOL;
+    uint32_t xlo[NS], xhi[NS];
+    float xfr[NS];
+    bool q_live[NQ];
+    uint32_t ooff[NQ];
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) {
+        const int q = (g0 + t) * 4 + ql;
+        q_live[t] = q < c.pw;
+        // columns past the crop: an offset no buffer range holds, the store is dropped
+        ooff[t] = q_live[t] ? (uint32_t)q * (uint32_t)c.C * 4u + c.chan_off : 0x80000000u;
+#pragma unroll
+        for (int k = 0; k < POOL; ++k) {
+            const int e = t * POOL + k;
+            const int tl = (t * 4 + ql) * POOL + k;          // sample's place in ux's tables
+            const int li = __shfl(ux.t_lo, tl), ri = __shfl(ux.t_hi, tl);
+            xfr[e] = __shfl(ux.t_fr, tl);
+            xlo[e] = (uint32_t)max(li, 0) * (RW_CS * 4u) + (uint32_t)cq * 16u;
+            xhi[e] = (uint32_t)max(ri, 0) * (RW_CS * 4u) + (uint32_t)cq * 16u;
+        }
+    }
+    const int npiece = (ux.n + 3) >> 2;                                   // uniform, 1..4
+    uint32_t voff[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int u = min(4 * p + ql, ux.n - 1);
+        voff[p] = (uint32_t)__shfl(ux.t_val, u) * c.sw_bytes + c.chan_off;
+    }
+    const int NR = rd.nr;
+    const unsigned nsy = (unsigned)c.nsy;
+    const f32x2 zero2 = {0.f, 0.f};
+    Quad best[NQ];
+    uchar4 arg[NQ];
+    Quad hA[NS], hB[NS];
+#pragma unroll
+    for (int e = 0; e < NS; ++e) { hA[e].a = hA[e].b = zero2; hB[e] = hA[e]; }
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) { best[t].a = best[t].b = zero2; arg[t] = make_uchar4(0, 0, 0, 0); }
+    unsigned sy = 0;
+    // vector memory operations issued so far, and that count right after each slot's staging
+    // loads: their difference is what may still be outstanding when the slot is read
+    int issued = 0;
+    int mark[ST_NSLOT];
+
+    auto fold = [&](unsigned s, const Quad (&v)[NS]) {
+        const unsigned ky = s % POOL;
+#pragma unroll
+        for (int t = 0; t < NQ; ++t) {
+            const Quad* w = &v[t * POOL];
+            if (WIN) {
+#pragma unroll
+                for (int kx = 0; kx < POOL; ++kx) {
+                    const int k = ky * POOL + kx;
+                    if (k == 0) {
+                        best[t] = w[kx];
+                        arg[t] = make_uchar4(0, 0, 0, 0);
+                    } else {
+                        if (w[kx].a.x > best[t].a.x) { best[t].a.x = w[kx].a.x; arg[t].x = k; }
+                        if (w[kx].a.y > best[t].a.y) { best[t].a.y = w[kx].a.y; arg[t].y = k; }
+                        if (w[kx].b.x > best[t].b.x) { best[t].b.x = w[kx].b.x; arg[t].z = k; }
+                        if (w[kx].b.y > best[t].b.y) { best[t].b.y = w[kx].b.y; arg[t].w = k; }
+                    }
+                }
+            } else if (POOL == 1) {
+                best[t] = w[0];
+            } else if (ky == 0) {
+                best[t].a.x = vmax2(w[0].a.x, w[POOL - 1].a.x);
+                best[t].a.y = vmax2(w[0].a.y, w[POOL - 1].a.y);
+                best[t].b.x = vmax2(w[0].b.x, w[POOL - 1].b.x);
+                best[t].b.y = vmax2(w[0].b.y, w[POOL - 1].b.y);
+            } else {
+                best[t].a.x = vmax3(best[t].a.x, w[0].a.x, w[POOL - 1].a.x);
+                best[t].a.y = vmax3(best[t].a.y, w[0].a.y, w[POOL - 1].a.y);
+                best[t].b.x = vmax3(best[t].b.x, w[0].b.x, w[POOL - 1].b.x);
+                best[t].b.y = vmax3(best[t].b.y, w[0].b.y, w[POOL - 1].b.y);
+            }
+        }
+        if (ky == POOL - 1) {
+            const uint32_t orow = (s / POOL) * c.orow_bytes;                           // uniform
+            issued = __builtin_amdgcn_readfirstlane(issued + NQ * (WIN ? 2 : 1));
+#pragma unroll
+            for (int t = 0; t < NQ; ++t) {
+                buf_store4(c.obuf, ooff[t], orow,
+                           make_float4(best[t].a.x, best[t].a.y, best[t].b.x, best[t].b.y));
+                if (WIN && q_live[t])
+                    *reinterpret_cast<uchar4*>(c.winner_roi + ((orow + ooff[t]) >> 2)) = arg[t];
+            }
+        }
+    };
+    auto stage_row = [&](int j, auto slot_c) {
+        constexpr int slot = decltype(slot_c)::value;
+        const uint32_t roff = (uint32_t)rl(rd.t_row, j) * c.row_bytes;                 // uniform
+        lds_dma_pieces(c.img_dma, voff[0], voff[1], voff[2], voff[3], roff,
+                       c.ring_addr + (uint32_t)slot * ST_SLOT_BYTES, npiece);
+        issued += npiece;
+        mark[slot] = issued;
+    };
+    auto step = [&](int j, auto slot_c, Quad (&hc)[NS], const Quad (&hp)[NS]) {
+        constexpr int slot = decltype(slot_c)::value;
+        wait_vm_at_most(issued - mark[slot]);              // row j has landed in its slot
+        const unsigned char* sp = c.ring + slot * ST_SLOT_BYTES;
+        Quad cl[NS], cr[NS];
+#pragma unroll
+        for (int e = 0; e < NS; ++e) {
+            cl[e] = quad_load_lds(sp + xlo[e]);
+            cr[e] = quad_load_lds(sp + xhi[e]);
+        }
+        asm volatile("" ::: "memory");
+        if (j + ST_NSLOT - 1 < NR)                         // into the slot read one step ago
+            stage_row(j + ST_NSLOT - 1, IntTag<(slot + ST_NSLOT - 1) % ST_NSLOT>{});
+#pragma unroll
+        for (int e = 0; e < NS; ++e) hc[e] = quad_lerp(cl[e], cr[e], xfr[e]);
+        while (sy < nsy && rl(rd.t_hi, sy) == j) {        // sample rows whose ceil row this is
+            const float fr = rlf(rd.t_fr, sy);
+            Quad v[NS];
+#pragma unroll
+            for (int e = 0; e < NS; ++e) v[e] = quad_lerp(hp[e], hc[e], fr);
+            fold(sy, v);
+            ++sy;
+        }
+    };
+    // steps j .. j+U-1 with compile-time slot and ping-pong parity
+    constexpr int U = (ST_NSLOT % 2) ? 2 * ST_NSLOT : ST_NSLOT;
+    auto chain = [&](auto self, auto uc, int j) -> void {
+        constexpr int u = decltype(uc)::value;
+        if constexpr (u < U) {
+            if (j + u < NR) {
+                if constexpr (u & 1) step(j + u, IntTag<u % ST_NSLOT>{}, hB, hA);
+                else                 step(j + u, IntTag<u % ST_NSLOT>{}, hA, hB);
+                self(self, IntTag<u + 1>{}, j);
+            }
+        }
+    };
+    auto prologue = [&](auto self, auto ic) -> void {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (i < ST_NSLOT - 1) {
+            if (i < NR) stage_row(i, IntTag<i>{});
+            self(self, IntTag<i + 1>{});
+        }
+    };
+#pragma unroll 1
+    for (int sub = 0; sub < c.nsub; ++sub) {
+        sy = 0;
+        issued = 0;
+#pragma unroll
+        for (int i = 0; i < ST_NSLOT; ++i) mark[i] = 0;
+        prologue(prologue, IntTag<0>{});
+#pragma unroll 1
+        for (int j = 0; j < NR; j += U) chain(chain, IntTag<0>{}, j);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) voff[p] += RW_CS * 4;
+#pragma unroll
+        for (int t = 0; t < NQ; ++t) ooff[t] += RW_CS * 4;
+    }
+}
+
+template <int POOL, bool WIN>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRCNN_ST_WPE, FRCNN_ST_WPE)))
+roi_fwd_stage_kernel(const float* __restrict__ fmap, int H, int W, int C, long long sb, long long sh,
+                     long long sw, const float4* __restrict__ rois, int R, int ch, int cw,
+                     int ngrp, int nsub, float* __restrict__ out, uint8_t* __restrict__ winner) {
+    // ngrp workgroups per RoI, each walks nsub consecutive 64-channel slices
+    __shared__ __attribute__((aligned(1024))) unsigned char st_ring[ST_NSLOT * ST_SLOT_BYTES];
+    const int lane = threadIdx.x;
+    const int slice = (blockIdx.x % ngrp) * nsub, r = blockIdx.x / ngrp, b = blockIdx.y;
+    StageCtx c;
+    c.box = rois[(size_t)b * R + r];
+    const RowDup rd = build_row_dup(c.box.x, c.box.z, H, ch);
+    const bool flipped = c.box.z < c.box.x || c.box.w < c.box.y;
+    c.nsub = nsub;
+    c.W = W; c.C = C; c.cw = cw;
+    c.ph = ch / POOL; c.pw = cw / POOL; c.nsy = c.ph * POOL;
+    c.row_bytes = (uint32_t)sh * 4u;
+    c.sw_bytes = (uint32_t)sw * 4u;
+    const int cq = lane & (RW_LANES - 1), ql = lane / RW_LANES;
+    c.chan_off = (uint32_t)(slice * RW_CS + cq * 4) * 4u;
+    c.orow_bytes = (uint32_t)c.pw * (uint32_t)C * 4u;
+    const size_t oroi = ((size_t)b * R + r) * (size_t)(c.ph * c.pw) * C;
+#ifdef FRCNN_ST_NOSTORE      // timing experiment: zero records, every store is dropped
+    c.obuf = __builtin_amdgcn_make_buffer_rsrc(out + oroi, 0, 0, 0x00020000);
+#else
+    c.obuf = __builtin_amdgcn_make_buffer_rsrc(out + oroi, 0, (uint32_t)c.ph * c.orow_bytes, 0x00020000);
+#endif
+    c.winner_roi = WIN ? winner + oroi : nullptr;
+    c.ring = st_ring;
+    c.ring_addr = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_void_ptr)st_ring);
+    const float* img_ptr = fmap + (size_t)b * sb;
+    const uint64_t img_addr = (uint64_t)(uintptr_t)img_ptr;
+    c.img_dma.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)img_addr);
+    c.img_dma.y = __builtin_amdgcn_readfirstlane((int)((uint32_t)(img_addr >> 32) & 0xFFFFu));
+#ifdef FRCNN_ST_NOLOAD       // timing experiment: zero records, every staging load is dropped
+    c.img_dma.z = 0;
+#else
+    c.img_dma.z = __builtin_amdgcn_readfirstlane((int)((uint32_t)H * c.row_bytes));
+#endif
+    c.img_dma.w = 0x00020000;
+    const int ngroup = (c.pw + 3) >> 2;
+
+    if (flipped) {
+        // descending rows or columns: fetch every corner directly, four pooled columns at a time
+        c.rw = build_row_walk(c.box.x, c.box.z, H, ch);
+        const __amdgpu_buffer_rsrc_t img = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(img_ptr), 0, (uint32_t)H * c.row_bytes, 0x00020000);
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int sub = 0; sub < nsub; ++sub, c.chan_off += RW_CS * 4)
+        for (int g = 0; g < ngroup; ++g) {
+            const int q = g * 4 + ql;
+            uint32_t xlo[POOL], xhi[POOL];
+            float xfr[POOL];
+            bool xok[POOL];
+#pragma unroll
+            for (int k = 0; k < POOL; ++k) {
+                int lo = 0, hi = 0, ok = 0;
+                float fr = 0.f;
+                const int sx = q * POOL + k;
+                if (sx < cw) axis_sample(c.box.y, c.box.w, W, cw, sx, lo, hi, fr, ok);
+                xlo[k] = (uint32_t)lo * c.sw_bytes + c.chan_off;
+                xhi[k] = (uint32_t)hi * c.sw_bytes + c.chan_off;
+                xfr[k] = fr;
+                xok[k] = sx < cw && ok;
+            }
+            float4 best = zero;
+            uchar4 arg = make_uchar4(0, 0, 0, 0);
+            for (int sy = 0; sy < c.nsy; ++sy) {
+                const int lo = rl(c.rw.t_lo, sy), hi = rl(c.rw.t_hi, sy);
+                const float fr = rlf(c.rw.t_fr, sy);
+#pragma unroll
+                for (int k = 0; k < POOL; ++k) {
+                    float4 v = zero;
+                    if (lo >= 0 && xok[k]) {
+                        const int rlo = c.rw.walk ? rl(c.rw.t_row, lo) : lo;
+                        const int rhi = c.rw.walk ? rl(c.rw.t_row, hi) : hi;
+                        const uint32_t rt = (uint32_t)rlo * c.row_bytes, rb = (uint32_t)rhi * c.row_bytes;
+                        const float4 top = lerp4(buf_load4(img, xlo[k], rt), buf_load4(img, xhi[k], rt),
+                                                 xfr[k]);
+                        const float4 bot = lerp4(buf_load4(img, xlo[k], rb), buf_load4(img, xhi[k], rb),
+                                                 xfr[k]);
+                        v = lerp4(top, bot, fr);
+                    }
+                    const int kk = (sy % POOL) * POOL + k;
+                    if (kk == 0) {
+                        best = v;
+                        arg = make_uchar4(0, 0, 0, 0);
+                    } else {
+                        if (v.x > best.x) { best.x = v.x; arg.x = kk; }
+                        if (v.y > best.y) { best.y = v.y; arg.y = kk; }
+                        if (v.z > best.z) { best.z = v.z; arg.z = kk; }
+                        if (v.w > best.w) { best.w = v.w; arg.w = kk; }
+                    }
+                }
+                if (sy % POOL == POOL - 1 && q < c.pw) {
+                    const uint32_t o = (uint32_t)(sy / POOL) * c.orow_bytes +
+                                       (uint32_t)q * (uint32_t)C * 4u + c.chan_off;
+                    *reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(out + oroi) + o) = best;
+                    if (WIN) *reinterpret_cast<uchar4*>(c.winner_roi + (o >> 2)) = arg;
+                }
+            }
         }
         return;
     }
 
-    const int NR = rw.nr;
-    float4 hA[POOL], hB[POOL], lAl[POOL], lAr[POOL], lBl[POOL], lBr[POOL];
-#pragma unroll
-    for (int k = 0; k < POOL; ++k) { hA[k] = hB[k] = lAl[k] = lAr[k] = lBl[k] = lBr[k] = zero; }
-    int sy = 0;
-
-    auto load_row = [&](int j, float4 (&ll)[POOL], float4 (&lr)[POOL]) {
-        const uint32_t roff = (uint32_t)rl(rw.t_row, j) * row_bytes + sub_off;          // uniform
-#pragma unroll
-        for (int k = 0; k < POOL; ++k) {
-            ll[k] = buf_load4(img, xlo[k], roff);
-            lr[k] = buf_load4(img, xhi[k], roff);
-        }
-    };
-    // finish every sample row that needs nothing beyond unique row j
-    auto drain = [&](int j, const float4 (&hc)[POOL], const float4 (&hp)[POOL], auto xtag) {
-        constexpr bool XALL = decltype(xtag)::value;
-        while (sy < nsy) {
-            const int lo = rl(rw.t_lo, sy), hi = rl(rw.t_hi, sy);
-            if (lo >= 0 && hi > j) break;
-            const float fr = rlf(rw.t_fr, sy);
-            if (lo < 0) {
-                float4 v[POOL];
-#pragma unroll
-                for (int k = 0; k < POOL; ++k) v[k] = zero;
-                fold(sy, v);
-            } else if (lo == j) {
-                float4 v[POOL];
-#pragma unroll
-                for (int k = 0; k < POOL; ++k) {
-                    v[k] = lerp4(hc[k], hc[k], fr);
-                    if (!XALL && !xok[k]) v[k] = zero;
-                }
-                fold(sy, v);
-            } else {
-                float4 v[POOL];
-#pragma unroll
-                for (int k = 0; k < POOL; ++k) {
-                    v[k] = lerp4(hp[k], hc[k], fr);
-                    if (!XALL && !xok[k]) v[k] = zero;
-                }
-                fold(sy, v);
+    int g = 0;
+#pragma unroll 1
+    while (g < ngroup) {
+        if (FRCNN_ST_PAIR && rd.all_valid && g + 1 < ngroup) {
+            const AxisUnique u2 = axis_unique(c.box.y, c.box.w, W, cw, g * 4 * POOL, 8 * POOL);
+            const bool cols_in = __all(lane >= 8 * POOL || g * 4 * POOL + lane >= cw || u2.t_lo >= 0);
+            if (cols_in && u2.n <= ST_CELLS) {            // uniform
+                staged_walk_hot<POOL, WIN, 2>(c, rd, u2, g);
+                g += 2;
+                continue;
             }
-            ++sy;
         }
-    };
-    auto step = [&](int j, float4 (&hc)[POOL], const float4 (&hp)[POOL], const float4 (&cl)[POOL],
-                    const float4 (&cr)[POOL], float4 (&nl)[POOL], float4 (&nr_)[POOL], auto xtag) {
-        load_row(min(j + 1, NR - 1), nl, nr_);          // next row in flight (last row: reloaded)
-#pragma unroll
-        for (int k = 0; k < POOL; ++k) hc[k] = lerp4(cl[k], cr[k], xfr[k]);
-        drain(j, hc, hp, xtag);
-    };
-    auto run = [&](auto xtag) {
-        sy = 0;
-        drain(-1, hA, hB, xtag);                         // leading extrapolated sample rows
-        if (NR > 0) load_row(0, lAl, lAr);
-#pragma unroll 1
-        for (int j = 0; j < NR; j += 2) {
-            step(j, hA, hB, lAl, lAr, lBl, lBr, xtag);
-            if (j + 1 < NR) step(j + 1, hB, hA, lBl, lBr, lAl, lAr, xtag);
+        const AxisUnique u1 = axis_unique(c.box.y, c.box.w, W, cw, g * 4 * POOL, 4 * POOL);
+        const bool cols_in = __all(lane >= 4 * POOL || g * 4 * POOL + lane >= cw || u1.t_lo >= 0);
+        if (rd.all_valid && cols_in) {
+            staged_walk_hot<POOL, WIN, 1>(c, rd, u1, g);
+        } else {
+            c.rw = build_row_walk(c.box.x, c.box.z, H, ch);
+            staged_walk<POOL, WIN, 1>(c, u1, g);
         }
-        drain(NR, hA, hB, xtag);                         // trailing extrapolated sample rows
-    };
-#pragma unroll 1
-    for (int sub = 0; sub < nsub; ++sub, sub_off += RW_CS * 4) {
-        if (wave_xall) run(BoolTag<true>{}); else run(BoolTag<false>{});
+        g += 1;
     }
 }
 
@@ -667,15 +1141,13 @@ extern "C" int frcnn_roi_crop_pool_fwd(const float* fmap, int B, int H, int W, i
                            (long long)W * sw * 4 + (long long)C * 4 < 0x7FFFFFFFll &&
                            (long long)(crop_h / pool) * (crop_w / pool) * C * 4 < 0x7FFFFFFFll;
     if (walk_path) {
-        // 64-channel sub-slices walked by one workgroup.  2, 4 and 8 measured no faster than 1
-        // (the kernel is bound by the texture addresser, not by the per-RoI set-up).
-        const int nsub = 1;
-        const int nslice = C / (RW_CS * nsub);
-        const int pw = crop_w / pool;
-        const dim3 g3((unsigned)(R * nslice), B), b3(64 * ((pw + 3) / 4));
+        const int nslice = C / RW_CS;
+        const int nsub = FRCNN_ST_NSUB <= nslice && nslice % FRCNN_ST_NSUB == 0 ? FRCNN_ST_NSUB : 1;
+        const int ngrp = nslice / nsub;
+        const dim3 g3((unsigned)(R * ngrp), B), b3(64);
 #define FRCNN_WALK(P, WN)                                                                       \
-    FRCNN_LAUNCH((roi_fwd_walk_kernel<P, WN>), g3, b3, 0, st, fmap, H, W, C, (long long)sb,     \
-                 (long long)sh, (long long)sw, rb, R, crop_h, crop_w, nslice, nsub, out, winner)
+    FRCNN_LAUNCH((roi_fwd_stage_kernel<P, WN>), g3, b3, 0, st, fmap, H, W, C, (long long)sb,    \
+                 (long long)sh, (long long)sw, rb, R, crop_h, crop_w, ngrp, nsub, out, winner)
         if (pool == 2) { if (winner) FRCNN_WALK(2, true); else FRCNN_WALK(2, false); }
         else           { FRCNN_WALK(1, false); }
 #undef FRCNN_WALK

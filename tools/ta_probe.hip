@@ -18,10 +18,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // mode 4: all lanes, every 16-lane group reads the SAME 256 bytes
 // mode 5: even 16-lane groups only (0..15, 32..47)
 // mode 6: LDS ds_read_b128, all lanes, conflict-free
+// mode 7: direct-to-LDS 16-byte loads (1 KiB per wave instruction), 4 x 256 B segments
+// mode 8: register load + ds_write_b128 of the same data
 template <int MODE>
 __global__ void __launch_bounds__(256) probe(const float* __restrict__ src, int cells, int iters,
                                              float* __restrict__ sink) {
-    __shared__ f32x4 lds[1024];
+    __shared__ f32x4 lds[2048];
     const int lane = threadIdx.x & 63;
     const int grp = lane >> 4, cq = lane & 15;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -49,16 +51,36 @@ __global__ void __launch_bounds__(256) probe(const float* __restrict__ src, int 
                 else voff = (uint32_t)grp * 2048u * 3u + (uint32_t)cq * 16u;
                 if (MODE == 6) {
                     v[u] = lds[(lane + u * 64 + it) & 1023];
+                } else if (MODE == 7) {
+                    uint32_t soff = c * 2048u;
+                    if (c + 9 >= (uint32_t)cells) soff = 0;
+                    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        rs, (__attribute__((address_space(3))) void*)&lds[(w * 8 + u) * 64], 16, voff, soff, 0, 0);
+                    v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                } else if (MODE == 8) {
+                    uint32_t soff = c * 2048u;
+                    if (c + 9 >= (uint32_t)cells) soff = 0;
+                    v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
                 } else {
                     uint32_t soff = c * 2048u;
                     if (MODE != 3 && MODE != 4 && c + 9 >= (uint32_t)cells) soff = 0;
                     v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
                 }
             }
+            if (MODE == 8) {
+                const int w = threadIdx.x >> 6;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) lds[(w * 8 + u) * 64 + lane] = v[u];
+            }
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc += v[u];
             cell = (cell + 41u) % (uint32_t)cells;
         }
+    }
+    if (MODE == 7 || MODE == 8) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        acc += lds[threadIdx.x];
     }
     if (acc.x == 12345.678f) sink[threadIdx.x] = acc.x + acc.y + acc.z + acc.w;
 }
@@ -96,5 +118,7 @@ int main() {
     run<3>("all lanes, 1 KB contiguous", src, cells, sink, 64);
     run<4>("all lanes, 4 groups read the same 256 B", src, cells, sink, 64);
     run<6>("LDS ds_read_b128 all lanes", src, cells, sink, 64);
+    run<7>("direct-to-LDS dwordx4, 4 x 256 B segments", src, cells, sink, 64);
+    run<8>("register load + ds_write_b128", src, cells, sink, 64);
     return 0;
 }
