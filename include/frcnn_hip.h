@@ -204,6 +204,37 @@ int frcnn_detect_postprocess(const float* proposed, const float* cls_prob, const
                              int32_t* classes, int32_t* src, int32_t* count,
                              frcnn_stream_t stream);
 
+/* ---- next row f2: loss assembly ---------------------------------------------------------------
+ * RPN side.  Replaces Faster_RCNN/model_train.py:626-635 with the losses of :598-600
+ * (tf.keras.losses.BinaryCrossentropy on probabilities; Loss_bbr, module/loss.py:4-14):
+ * gather pred_obj [B,H*W*A] and pred_reg [B,H*W*A,4] at pos [B,S,3] i64 = (y,x,a) (the
+ * batch_pos of frcnn_rpn_sample); label [B,S] f32 (1 / 0); reg_gt [B,S,4].
+ *   loss[0] = mean over B*S of the binary cross-entropy (clip to [1e-7, 1-1e-7], +1e-7 in
+ *             the logs, as Keras does);
+ *   loss[1] = mean over the 4*P coordinates of the P samples with label 1 of smooth-L1
+ *             (threshold 1); 0 when P = 0;
+ *   loss[2] = 2*loss[0] + loss[1].
+ * partial [B,4] f32 receives per image {BCE sum, smooth-L1 sum, P, #out-of-range positions}.
+ * d_obj [B,H*W*A] / d_reg [B,H*W*A,4] (either may be NULL): d loss[2] / d prediction, zero at
+ * anchors outside the mini-batch (written in full by the call). */
+int frcnn_rpn_loss(const float* pred_obj, const float* pred_reg, const int64_t* pos,
+                   const float* label, const float* reg_gt, int B, int H, int W, int A, int S,
+                   float* loss, float* partial, float* d_obj, float* d_reg,
+                   frcnn_stream_t stream);
+
+/* Head side.  Replaces Faster_RCNN/model_train.py:639-657 (CategoricalCrossentropy on
+ * probabilities: row normalised by its sum, clipped to [1e-7, 1-1e-7]):
+ * cls_prob [B,R,K], reg [B,R,K,4] gathered at tindex [B,S] i64 and, for the regression, at
+ * class argmax(label) (first maximum); label [B,S,K] f32; gt_mask [B,S] i32 (non-zero =
+ * foreground); gt_coord [B,S,4] (clipped to [-100,100] here, model_train.py:643).
+ * loss / partial as above (means over B*S rows and over 4*P coordinates).
+ * d_cls [B,R,K] / d_reg [B,R,K,4] (either may be NULL): d loss[2] / d prediction, written in
+ * full.  K <= 64. */
+int frcnn_head_loss(const float* cls_prob, const float* reg, const int64_t* tindex,
+                    const float* label, const int32_t* gt_mask, const float* gt_coord,
+                    int B, int R, int S, int K, float* loss, float* partial,
+                    float* d_cls, float* d_reg, frcnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

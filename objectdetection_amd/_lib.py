@@ -57,6 +57,8 @@ _SIGS = {
     "frcnn_sample_proposals": (_i, [_p, _i, _i, _i, _p, _p, _p, _u64, _i, _i, _i, _p, _p, _p]),
     "frcnn_detect_postprocess": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p, _p, _p, _p, _p,
                                       _p, _p, _p]),
+    "frcnn_rpn_loss": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
+    "frcnn_head_loss": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
 }
 
 for _name, (_res, _args) in _SIGS.items():

@@ -309,3 +309,52 @@ def detect_postprocess(proposed: torch.Tensor, cls_prob: torch.Tensor, reg: torc
             _ptr(out["decoded"]), _ptr(out["cls_arg"]), _ptr(out["boxes"]), _ptr(out["scores"]),
             _ptr(out["classes"]), _ptr(out["src"]), _ptr(out["count"]), _stream(p)))
     return out
+
+
+def rpn_loss(pred_obj: torch.Tensor, pred_reg: torch.Tensor, pos: torch.Tensor,
+             label: torch.Tensor, reg_gt: torch.Tensor, want_grad: bool = True):
+    """pred_obj [B,H,W,A], pred_reg [B,H,W,A,4] (or 4A packed), pos [B,S,3] i64, label [B,S],
+    reg_gt [B,S,4] -> dict(loss [3] = (cls, reg, 2*cls+reg), partial [B,4], d_obj, d_reg)."""
+    po = _cont(pred_obj, "pred_obj", torch.float32)
+    B, H, W, A = po.shape
+    pr = _cont(pred_reg, "pred_reg", torch.float32).reshape(B, H, W, A, 4)
+    ps = _cont(pos, "pos", torch.int64)
+    S = ps.shape[1]
+    lb = _cont(label, "label", torch.float32).reshape(B, S)
+    rg = _cont(reg_gt, "reg_gt", torch.float32).reshape(B, S, 4)
+    dev = po.device
+    out = dict(loss=torch.empty(3, dtype=torch.float32, device=dev),
+               partial=torch.empty((B, 4), dtype=torch.float32, device=dev),
+               d_obj=torch.empty_like(po) if want_grad else None,
+               d_reg=torch.empty_like(pr) if want_grad else None)
+    with torch.cuda.device(dev):
+        check("frcnn_rpn_loss", lib.frcnn_rpn_loss(
+            _ptr(po), _ptr(pr), _ptr(ps), _ptr(lb), _ptr(rg), B, H, W, A, S, _ptr(out["loss"]),
+            _ptr(out["partial"]), _ptr(out["d_obj"]), _ptr(out["d_reg"]), _stream(po)))
+    return out
+
+
+def head_loss(cls_prob: torch.Tensor, reg: torch.Tensor, tindex: torch.Tensor,
+              label: torch.Tensor, gt_mask: torch.Tensor, gt_coord: torch.Tensor,
+              want_grad: bool = True):
+    """cls_prob [B,R,K], reg [B,R,K*4], tindex [B,S] i64, label [B,S,K], gt_mask [B,S],
+    gt_coord [B,S,4] -> dict(loss [3], partial [B,4], d_cls [B,R,K], d_reg [B,R,K,4])."""
+    cp = _cont(cls_prob, "cls_prob", torch.float32)
+    B, R, K = cp.shape
+    rg = _cont(reg, "reg", torch.float32).reshape(B, R, K, 4)
+    ti = _cont(tindex, "tindex", torch.int64)
+    S = ti.shape[1]
+    lb = _cont(label, "label", torch.float32).reshape(B, S, K)
+    gm = _cont(gt_mask.to(torch.int32), "gt_mask", torch.int32).reshape(B, S)
+    gc = _cont(gt_coord, "gt_coord", torch.float32).reshape(B, S, 4)
+    dev = cp.device
+    out = dict(loss=torch.empty(3, dtype=torch.float32, device=dev),
+               partial=torch.empty((B, 4), dtype=torch.float32, device=dev),
+               d_cls=torch.empty_like(cp) if want_grad else None,
+               d_reg=torch.empty_like(rg) if want_grad else None)
+    with torch.cuda.device(dev):
+        check("frcnn_head_loss", lib.frcnn_head_loss(
+            _ptr(cp), _ptr(rg), _ptr(ti), _ptr(lb), _ptr(gm), _ptr(gc), B, R, S, K,
+            _ptr(out["loss"]), _ptr(out["partial"]), _ptr(out["d_cls"]), _ptr(out["d_reg"]),
+            _stream(cp)))
+    return out

@@ -714,3 +714,98 @@ def detect_postprocess(proposed, cls_prob, reg, bg_label=20, max_out=30, iou_thr
         src[b, :n] = fg[sel]
     return dict(boxes=boxes, scores=scores, classes=classes, src=src, count=count, decoded=result,
                 argindex=argindex.astype(np.int32))
+
+
+# --------------------------------------------------------------------------
+# next row f2: loss assembly (model_train.py:598-600, 626-635, 639-657)
+# --------------------------------------------------------------------------
+KERAS_EPS = F32(1e-7)
+
+
+def loss_bbr(y_true, y_pred):
+    """module/loss.py:9-14 (threshold 1): element-wise smooth-L1 and d/d(y_pred)."""
+    e = (np.asarray(y_true, F32) - np.asarray(y_pred, F32)).astype(F32)
+    ae = np.abs(e)
+    small = ae < F32(1)
+    val = np.where(small, e * e / F32(2), F32(1) * ae - F32(0.5)).astype(F32)
+    grad = np.where(small, -e, np.where(e > 0, F32(-1), F32(1))).astype(F32)
+    return val, grad
+
+
+def keras_bce(y, p):
+    """tf.keras.backend.binary_crossentropy on probabilities (eager path): clip to
+    [eps, 1-eps], -(y log(p+eps) + (1-y) log(1-p+eps)); value and d/dp (clip_by_value passes
+    the gradient on [eps, 1-eps])."""
+    y = np.asarray(y, F32)
+    p = np.asarray(p, F32)
+    pc = np.clip(p, KERAS_EPS, F32(1) - KERAS_EPS).astype(F32)
+    a = (pc + KERAS_EPS).astype(F32)
+    b = (F32(1) - pc + KERAS_EPS).astype(F32)
+    v = (y * np.log(a)).astype(F32)
+    v = (v + (F32(1) - y) * np.log(b)).astype(F32)
+    inside = (p >= KERAS_EPS) & (p <= F32(1) - KERAS_EPS)
+    g = np.where(inside, -(y / a - (F32(1) - y) / b), F32(0)).astype(F32)
+    return (-v).astype(F32), g
+
+
+def keras_cce(y, p):
+    """tf.keras.backend.categorical_crossentropy on probabilities: q = p / sum(p), clip,
+    -sum(y log q); value [...,] and d/dp [..., K]."""
+    y = np.asarray(y, F32)
+    p = np.asarray(p, F32)
+    sp = p.sum(-1, keepdims=True, dtype=np.float64).astype(F32)
+    q = (p / sp).astype(F32)
+    qc = np.clip(q, KERAS_EPS, F32(1) - KERAS_EPS).astype(F32)
+    val = -(y * np.log(qc)).sum(-1, dtype=np.float64)
+    inside = (q >= KERAS_EPS) & (q <= F32(1) - KERAS_EPS)
+    g = np.where(inside, -y / qc, F32(0)).astype(np.float64)        # dL/dq
+    gp = (g * p).sum(-1, keepdims=True)
+    dp = g / sp - gp / (sp.astype(np.float64) ** 2)
+    return val, dp
+
+
+def rpn_loss(pred_obj, pred_reg, pos, label, reg_gt):
+    """model_train.py:626-635.  pred_obj [B,H,W,A], pred_reg [B,H,W,A,4], pos [B,S,3],
+    label [B,S], reg_gt [B,S,4] -> (cls, reg, total), d_obj, d_reg (float64 sums)."""
+    B, H, W, A = pred_obj.shape
+    S = pos.shape[1]
+    bi = np.repeat(np.arange(B), S)
+    y, x, a = pos.reshape(-1, 3).T
+    p = pred_obj[bi, y, x, a]
+    lab = np.asarray(label, F32).reshape(-1)
+    v, g = keras_bce(lab, p)
+    cls = v.sum(dtype=np.float64) / (B * S)
+    is_pos = lab.astype(np.int64) == 1
+    hv, hg = loss_bbr(reg_gt.reshape(-1, 4)[is_pos], pred_reg[bi, y, x, a][is_pos])
+    P = int(is_pos.sum())
+    reg = hv.sum(dtype=np.float64) / (4 * P) if P else 0.0
+    d_obj = np.zeros(pred_obj.shape, np.float64)
+    d_obj[bi, y, x, a] = 2.0 * g / (B * S)
+    d_reg = np.zeros(pred_reg.shape, np.float64)
+    if P:
+        d_reg[bi[is_pos], y[is_pos], x[is_pos], a[is_pos]] = hg / (4.0 * P)
+    return (cls, reg, 2.0 * cls + reg), d_obj, d_reg
+
+
+def head_loss(cls_prob, reg, tindex, label, gt_mask, gt_coord):
+    """model_train.py:639-657.  cls_prob [B,R,K], reg [B,R,K,4], tindex [B,S], label
+    [B,S,K], gt_mask [B,S], gt_coord [B,S,4] -> (cls, reg, total), d_cls, d_reg."""
+    B, R, K = cls_prob.shape
+    S = tindex.shape[1]
+    bi = np.repeat(np.arange(B), S)
+    r = np.asarray(tindex).reshape(-1)
+    lab = np.asarray(label, F32).reshape(-1, K)
+    v, dp = keras_cce(lab, cls_prob[bi, r])
+    cls = v.sum() / (B * S)
+    m = np.asarray(gt_mask).reshape(-1) != 0
+    c = lab.argmax(-1)
+    gt = np.clip(np.asarray(gt_coord, F32).reshape(-1, 4), F32(-100), F32(100))
+    hv, hg = loss_bbr(gt[m], reg[bi, r, c][m])
+    P = int(m.sum())
+    lreg = hv.sum(dtype=np.float64) / (4 * P) if P else 0.0
+    d_cls = np.zeros(cls_prob.shape, np.float64)
+    d_cls[bi, r] = 2.0 * dp / (B * S)
+    d_reg = np.zeros(reg.shape, np.float64)
+    if P:
+        d_reg[bi[m], r[m], c[m]] = hg / (4.0 * P)
+    return (cls, lreg, 2.0 * cls + lreg), d_cls, d_reg
