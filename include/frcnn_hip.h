@@ -235,6 +235,27 @@ int frcnn_head_loss(const float* cls_prob, const float* reg, const int64_t* tind
                     int B, int R, int S, int K, float* loss, float* partial,
                     float* d_cls, float* d_reg, frcnn_stream_t stream);
 
+/* ---- next row f3: input side -------------------------------------------------------------------
+ * Replaces Faster_RCNN/module/data.py:9-52 (data_preprocess / augmentation_data /
+ * random_augmentation) and the padding of shipdetection/train.py:36-37 for a batch:
+ * boxes [total,4] f32 and labels [total] i64 (may be NULL) hold every image's objects back to
+ * back, image b owning rows offsets[b] .. offsets[b+1]-1 (offsets [B+1] i32).  Output
+ * gt [B,G,4] / gt_label [B,G] (may be NULL): the first G objects, zero padded; count [B] i32
+ * (may be NULL) = objects the image has (more than G: the rest is dropped; the reference
+ * raises on a negative pad there).  With use_flip != 0 the boxes of a flipped image become
+ * [ymin, 1-xmax, ymax, 1-xmin] BEFORE padding (padding rows stay 0).  Flip decision:
+ * flip [B] u8, or NULL -> Philox counter key (stream 6, image image_base+b) > 2^31, the
+ * "uniform > 0.5" of module/data.py:44-45. */
+int frcnn_pad_gt(const float* boxes, const int64_t* labels, const int32_t* offsets,
+                 const uint8_t* flip, int use_flip, uint64_t seed, int image_base,
+                 int B, int G, float* gt, int64_t* gt_label, int32_t* count,
+                 frcnn_stream_t stream);
+
+/* tf.image.flip_left_right on the images the same decision flips (module/data.py:25):
+ * images / out [B,H,W,C] f32 contiguous, out != images; images not flipped are copied. */
+int frcnn_flip_images(const float* images, const uint8_t* flip, uint64_t seed, int image_base,
+                      int B, int H, int W, int C, float* out, frcnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -109,3 +109,43 @@ def making_frcnn_input(gt_box: torch.Tensor, label: torch.Tensor, fmap: torch.Te
     gt_coord2 = torch.gather(lab["gt_coord"], 1, tindex.unsqueeze(-1).expand(-1, -1, 4))
     gt_mask2 = torch.gather(lab["gt_mask"], 1, tindex)
     return crop_fmap, gt_label2, gt_mask2, gt_coord2, proposed, tindex
+
+
+# ---- input side (module/data.py:9-52), batched -------------------------------------------
+def _ragged(bboxes, labels, device):
+    """Lists of per-image [n_i,4] boxes / [n_i] labels -> (boxes, labels, offsets) on device."""
+    counts = [int(torch.as_tensor(b).reshape(-1, 4).shape[0]) for b in bboxes]
+    offsets = torch.zeros(len(counts) + 1, dtype=torch.int32)
+    offsets[1:] = torch.tensor(counts, dtype=torch.int32).cumsum(0)
+    cat = torch.cat([torch.as_tensor(b, dtype=torch.float32).reshape(-1, 4) for b in bboxes])
+    lab = None
+    if labels is not None:
+        lab = torch.cat([torch.as_tensor(l, dtype=torch.int64).reshape(-1) for l in labels])
+        lab = lab.to(device)
+    return cat.to(device), lab, offsets.to(device)
+
+
+def data_preprocess(images: torch.Tensor, bboxes, labels=None, cfg: PathConfig = REFERENCE):
+    """Batched counterpart of data_preprocess (module/data.py:9-21) without the resize:
+    images [B,H,W,C] on the device, bboxes / labels lists of per-image tensors.  Returns
+    {"image", "bbox" [B,G,4], "label" [B,G]} with zero padding to cfg.G."""
+    boxes, lab, off = _ragged(bboxes, labels, images.device)
+    gt, gl, _ = ops.pad_gt(boxes, lab, off, cfg.G)
+    return {"image": images, "bbox": gt, "label": gl}
+
+
+def augmentation_data(images: torch.Tensor, labels, bbox: torch.Tensor):
+    """module/data.py:23-33 for a batch: every image and its padded-free boxes [n,4] flipped."""
+    flip = torch.ones(images.shape[0], dtype=torch.uint8, device=images.device)
+    out = torch.stack([bbox[:, 0], 1 - bbox[:, 3], bbox[:, 2], 1 - bbox[:, 1]], 1)
+    return [ops.flip_images(images, flip), labels, out]
+
+
+def random_augmentation(images: torch.Tensor, bboxes, labels=None, cfg: PathConfig = REFERENCE,
+                        flip: Optional[torch.Tensor] = None, seed: int = 0, image_base: int = 0):
+    """Batched counterpart of random_augmentation (module/data.py:36-52) without the resize:
+    per image, flip image and boxes with probability 1/2 (`flip` [B] u8 makes the decision
+    explicit, else Philox counters from `seed`), then pad boxes / labels to cfg.G."""
+    boxes, lab, off = _ragged(bboxes, labels, images.device)
+    gt, gl, _ = ops.pad_gt(boxes, lab, off, cfg.G, flip, True, seed, image_base)
+    return {"image": ops.flip_images(images, flip, seed, image_base), "bbox": gt, "label": gl}

@@ -358,3 +358,43 @@ def head_loss(cls_prob: torch.Tensor, reg: torch.Tensor, tindex: torch.Tensor,
             _ptr(out["loss"]), _ptr(out["partial"]), _ptr(out["d_cls"]), _ptr(out["d_reg"]),
             _stream(cp)))
     return out
+
+
+def pad_gt(boxes: torch.Tensor, labels: Optional[torch.Tensor], offsets: torch.Tensor, G: int,
+           flip: Optional[torch.Tensor] = None, use_flip: bool = False, seed: int = 0,
+           image_base: int = 0):
+    """Ragged boxes [total,4] / labels [total] with offsets [B+1] -> (gt [B,G,4], gt_label
+    [B,G] i64 | None, count [B] i32); optional horizontal flip of the boxes."""
+    off = _cont(offsets, "offsets", torch.int32)
+    B = off.numel() - 1
+    dev = off.device
+    bx = _cont(boxes, "boxes", torch.float32).reshape(-1, 4)
+    if bx.shape[0] == 0:
+        bx = torch.zeros((1, 4), dtype=torch.float32, device=dev)
+    lb = None if labels is None else _cont(labels, "labels", torch.int64)
+    if lb is not None and lb.numel() == 0:
+        lb = torch.zeros(1, dtype=torch.int64, device=dev)
+    fl = None if flip is None else _cont(flip, "flip", torch.uint8)
+    gt = torch.empty((B, G, 4), dtype=torch.float32, device=dev)
+    gl = None if lb is None else torch.empty((B, G), dtype=torch.int64, device=dev)
+    cnt = torch.empty(B, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        check("frcnn_pad_gt", lib.frcnn_pad_gt(
+            _ptr(bx), _ptr(lb), _ptr(off), _ptr(fl), int(bool(use_flip)),
+            seed & 0xFFFFFFFFFFFFFFFF, image_base, B, G, _ptr(gt), _ptr(gl), _ptr(cnt),
+            _stream(off)))
+    return gt, gl, cnt
+
+
+def flip_images(images: torch.Tensor, flip: Optional[torch.Tensor] = None, seed: int = 0,
+                image_base: int = 0) -> torch.Tensor:
+    """images [B,H,W,C] f32 -> copy with the selected images flipped left-right."""
+    im = _cont(images, "images", torch.float32)
+    B, H, W, Cc = im.shape
+    fl = None if flip is None else _cont(flip, "flip", torch.uint8)
+    out = torch.empty_like(im)
+    with torch.cuda.device(im.device):
+        check("frcnn_flip_images", lib.frcnn_flip_images(
+            _ptr(im), _ptr(fl), seed & 0xFFFFFFFFFFFFFFFF, image_base, B, H, W, Cc, _ptr(out),
+            _stream(im)))
+    return out

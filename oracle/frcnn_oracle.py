@@ -809,3 +809,44 @@ def head_loss(cls_prob, reg, tindex, label, gt_mask, gt_coord):
     if P:
         d_reg[bi[m], r[m], c[m]] = hg / (4.0 * P)
     return (cls, lreg, 2.0 * cls + lreg), d_cls, d_reg
+
+
+# --------------------------------------------------------------------------
+# next row f3: input side (module/data.py:9-52, shipdetection/train.py:28-45)
+# --------------------------------------------------------------------------
+def flip_decision(seed, image_index):
+    """Build-defined replacement for `tf.random.uniform([]) > 0.5` (module/data.py:44-45):
+    Philox counter key (position 0, stream 6, image) above 2^31."""
+    return bool(random_keys(1, 6, image_index, seed)[0] > np.uint32(0x80000000))
+
+
+def augmentation_data(img, label, bbox):
+    """module/data.py:23-33: left-right flip of the image and of the boxes."""
+    image = None if img is None else np.asarray(img)[..., ::-1, :].copy()
+    b = np.asarray(bbox, F32)
+    xmin = (F32(1) - b[:, 3]).astype(F32)
+    xmax = (F32(1) - b[:, 1]).astype(F32)
+    return image, label, np.stack([b[:, 0], xmin, b[:, 2], xmax], 1).astype(F32)
+
+
+def pad_gt(bbox, label, G=42):
+    """module/data.py:13-18: zero padding of one image's boxes / labels to G rows (more than G
+    objects: the reference's negative pad raises; here the first G are kept)."""
+    b = np.asarray(bbox, F32).reshape(-1, 4)[:G]
+    out = np.zeros((G, 4), F32)
+    out[:len(b)] = b
+    lab = np.zeros(G, I64)
+    if label is not None:
+        l = np.asarray(label, I64)[:G]
+        lab[:len(l)] = l
+    return out, lab
+
+
+def random_augmentation(img, label, bbox, G=42, flip=None, seed=0, image_index=0):
+    """module/data.py:36-52 without the resize: optional flip, then padding."""
+    if flip is None:
+        flip = flip_decision(seed, image_index)
+    if flip:
+        img, label, bbox = augmentation_data(img, label, bbox)
+    b, l = pad_gt(bbox, label, G)
+    return img, b, l
