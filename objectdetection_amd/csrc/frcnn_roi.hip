@@ -723,7 +723,6 @@ roi_fwd_stage_kernel(const float* __restrict__ fmap, int H, int W, int C, long l
     const int slice = (blockIdx.x % ngrp) * nsub, r = blockIdx.x / ngrp, b = blockIdx.y;
     StageCtx c;
     c.box = rois[(size_t)b * R + r];
-    const RowDup rd = build_row_dup(c.box.x, c.box.z, H, ch);
     const bool flipped = c.box.z < c.box.x || c.box.w < c.box.y;
     c.nsub = nsub;
     c.W = W; c.C = C; c.cw = cw;
@@ -820,6 +819,8 @@ roi_fwd_stage_kernel(const float* __restrict__ fmap, int H, int W, int C, long l
     int g = 0;
 #pragma unroll 1
     while (g < ngroup) {
+        // rebuilt per walk rather than kept in registers across one
+        const RowDup rd = build_row_dup(c.box.x, c.box.z, H, ch);
         if (FRCNN_ST_PAIR && rd.all_valid && g + 1 < ngroup) {
             const AxisUnique u2 = axis_unique(c.box.y, c.box.w, W, cw, g * 4 * POOL, 8 * POOL);
             const bool cols_in = __all(lane >= 8 * POOL || g * 4 * POOL + lane >= cw || u2.t_lo >= 0);
