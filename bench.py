@@ -115,6 +115,9 @@ def main():
     ap.add_argument("--channels", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inference", action="store_true", help="skip the training-only stages")
+    ap.add_argument("--depth", type=int, default=2, choices=(1, 2),
+                    help="batches in flight: 2 overlaps the proposals of batch i+1 with the RoI "
+                         "kernel of batch i")
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend (gloo lets several ranks rehearse on one GPU)")
     args = ap.parse_args()
@@ -142,7 +145,7 @@ def main():
     cfg = workload_cfg()
     B, C = args.batch, args.channels
     fmap, score, coord, gt, label = make_inputs(cfg, B, C, device, seed=1000 + rank)
-    path = RegionProposalPath(cfg, B, C, device, train=not args.inference)
+    path = RegionProposalPath(cfg, B, C, device, train=not args.inference, depth=args.depth)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
 
@@ -152,13 +155,15 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
+    ready = torch.cuda.Event()           # the synthetic inputs are resident before the loop
+    ready.record(torch.cuda.current_stream(device))
     for w in range(args.warmup):
-        path.run(fmap, score, coord, gt, label, seed=w, image_base=rank * B)
+        path.run(fmap, score, coord, gt, label, seed=w, image_base=rank * B, inputs_ready=ready)
     sync()
     t0 = time.perf_counter()
     for k in range(args.steps):
         path.run(fmap, score, coord, gt, label, seed=100 + k, image_base=rank * B,
-                 roi_events=ev[k])
+                 roi_events=ev[k], inputs_ready=ready)
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -198,6 +203,7 @@ def main():
                             + ("inference stages only" if args.inference else
                                "with RPN + head target sampling (training forward)"),
                 "images_per_gpu_per_step": B,
+                "batches_in_flight": args.depth,
                 "mean_kept_proposals": kept,
             },
             "roofline": {

@@ -15,6 +15,15 @@ Stages 1-2 and 6-7 are the training-only part (`train=True`).  They do not feed
 stages 3-5, so they are issued on a second HIP stream: 1-2 run beside the top-k / NMS
 chain, 6-7 beside the RoI kernel, and the streams are joined with events before run()
 returns (still no host synchronisation).
+
+With `depth=2` consecutive batches are software-pipelined: stages 3-4 (latency-bound, a few
+dozen small launches) go to a proposal stream and write one of two buffer sets, so the
+proposals of batch i+1 are computed while the RoI kernel of batch i (bandwidth-bound, fills
+the chip) is still running on the caller's stream.  Results of a run() are valid on the
+caller's stream as before; the set they live in is reused two calls later.  The proposal
+stream has normal priority on purpose: a high-priority stream in this wait pattern stopped
+making progress on MI355X (ROCm 7.2) once earlier streams of the process shared the hardware
+queues.
 """
 from __future__ import annotations
 
@@ -35,12 +44,15 @@ def _p(t):
 class RegionProposalPath:
     def __init__(self, cfg: PathConfig = REFERENCE, batch: int = 1, channels: int = 512,
                  device="cuda", train: bool = True, want_winner: bool = False,
-                 fuse_pool: bool = True):
+                 fuse_pool: bool = True, depth: int = 1):
+        if depth not in (1, 2):
+            raise ValueError("depth must be 1 or 2")
         self.cfg, self.B, self.C = cfg, batch, channels
         self.device = torch.device(device)
-        self.train, self.fuse_pool = train, fuse_pool
+        self.train, self.fuse_pool, self.depth = train, fuse_pool, depth
         self.side = torch.cuda.Stream(self.device) if train else None
-        self._ev = [torch.cuda.Event() for _ in range(3)] if train else None
+        self.prop_stream = torch.cuda.Stream(self.device) if depth == 2 else None
+        self._calls = 0
         dev, B, N = self.device, batch, cfg.N
         f32, i32, i64, u8 = torch.float32, torch.int32, torch.int64, torch.uint8
         e = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
@@ -48,24 +60,33 @@ class RegionProposalPath:
         self.pool = cfg.pool if fuse_pool else 1
         ph, pw = cfg.crop[0] // self.pool, cfg.crop[1] // self.pool
         K, R = cfg.pre_k, cfg.post_n
-        self.top_scores, self.top_idx = e((B, K), f32), e((B, K), i32)
-        self.cand = e((B, K, 4), f32)
-        self.nms_ws = e((ops.nms_workspace_bytes(B, K, R),), u8)
-        self.proposed, self.keep_pos = e((B, R, 4), f32), e((B, R), i32)
-        self.keep_count = e((B,), i32)
         self.pooled = e((B, R, ph, pw, channels), f32)
         self.winner = e((B, R, ph, pw, channels), u8) if want_winner else None
-        if train:
-            S, S2 = cfg.rpn_batch, cfg.head_batch
-            self.max_iou, self.best_gt, self.flags = e((B, N), f32), e((B, N), i32), e((B, N), u8)
-            self.rpn = dict(label=e((B, S), f32), anchor=e((B, S, 4), f32), gt=e((B, S, 4), f32),
-                            gt_list=e((B, S), i64), pos=e((B, S, 3), i64), reg=e((B, S, 4), f32),
-                            counts=e((B, 4), i32))
-            self.p_label, self.gt_mask = e((B, R), i64), e((B, R), i32)
-            self.gt_onehot = e((B, R, cfg.num_classes), f32)
-            self.gt_coord = e((B, R, 4), f32)
-            self.p_best, self.p_iou = e((B, R), i32), e((B, R), f32)
-            self.tindex, self.head_counts = e((B, S2), i64), e((B, 4), i32)
+        self._sets = []
+        for _ in range(depth):
+            d = dict(top_scores=e((B, K), f32), top_idx=e((B, K), i32), cand=e((B, K, 4), f32),
+                     nms_ws=e((ops.nms_workspace_bytes(B, K, R),), u8),
+                     proposed=e((B, R, 4), f32), keep_pos=e((B, R), i32), keep_count=e((B,), i32),
+                     ev=[torch.cuda.Event() for _ in range(5)])
+            if train:
+                S, S2 = cfg.rpn_batch, cfg.head_batch
+                d.update(max_iou=e((B, N), f32), best_gt=e((B, N), i32), flags=e((B, N), u8),
+                         rpn=dict(label=e((B, S), f32), anchor=e((B, S, 4), f32),
+                                  gt=e((B, S, 4), f32), gt_list=e((B, S), i64),
+                                  pos=e((B, S, 3), i64), reg=e((B, S, 4), f32),
+                                  counts=e((B, 4), i32)),
+                         p_label=e((B, R), i64), gt_mask=e((B, R), i32),
+                         gt_onehot=e((B, R, cfg.num_classes), f32), gt_coord=e((B, R, 4), f32),
+                         p_best=e((B, R), i32), p_iou=e((B, R), f32),
+                         tindex=e((B, S2), i64), head_counts=e((B, 4), i32))
+            self._sets.append(d)
+        self._bind(self._sets[0])
+
+    def _bind(self, d):
+        """Expose one buffer set under the attribute names callers read results from."""
+        for k, v in d.items():
+            if k != "ev":
+                setattr(self, k, v)
 
     def _validate(self, fmap, score, coord, gt, label):
         cfg, B = self.cfg, self.B
@@ -90,54 +111,78 @@ class RegionProposalPath:
 
     def run(self, fmap: torch.Tensor, score: torch.Tensor, coord: torch.Tensor,
             gt: Optional[torch.Tensor] = None, label: Optional[torch.Tensor] = None,
-            seed: int = 0, image_base: int = 0, roi_events=None):
+            seed: int = 0, image_base: int = 0, roi_events=None, inputs_ready=None):
         """fmap [B,H,W,C] channels-last, score [B,H,W,A], coord [B,H,W,4A],
-        gt [B,G,4], label [B,G] i64 (both only when train).  Returns self."""
+        gt [B,G,4], label [B,G] i64 (both only when train).  Returns self.
+
+        inputs_ready: an event after which the inputs may be read.  Without it the inputs are
+        taken to be ready where the caller's stream stands at the call, which with depth=2
+        orders this batch's proposals behind everything already queued there (no overlap)."""
         cfg, B, N = self.cfg, self.B, self.cfg.N
         self._validate(fmap, score, coord, gt, label)
+        d = self._sets[self._calls % self.depth]
+        self._calls += 1
+        self._bind(d)
+        ev = d["ev"]
         main = torch.cuda.current_stream(self.device)
-        st = main.cuda_stream
+        prop = self.prop_stream if self.depth == 2 else main
+        st, ps = main.cuda_stream, prop.cuda_stream
         seed &= 0xFFFFFFFFFFFFFFFF
+        # inputs were produced on the caller's stream; this set's previous user (two calls
+        # ago) finished reading it before the point ev[4] marks
+        if inputs_ready is not None:
+            ready = inputs_ready
+        else:
+            ready = ev[0]
+            ready.record(main)
+        if self.depth == 2:
+            prop.wait_event(ready)
+            if self._calls > self.depth:
+                prop.wait_event(ev[4])
         if self.train:
             G = gt.shape[1]
             ss = self.side.cuda_stream
-            self._ev[0].record(main)
-            self.side.wait_event(self._ev[0])          # inputs were produced on the main stream
+            self.side.wait_event(ready)
+            if self.depth == 2 and self._calls > self.depth:
+                self.side.wait_event(ev[4])
             check("frcnn_iou_assign", lib.frcnn_iou_assign(
                 _p(self.anchor), N, _p(gt), B, G, cfg.rpn_pos_thr, cfg.rpn_neg_thr,
-                _p(self.max_iou), _p(self.best_gt), _p(self.flags), None, ss))
-            r = self.rpn
+                _p(d["max_iou"]), _p(d["best_gt"]), _p(d["flags"]), None, ss))
+            r = d["rpn"]
             check("frcnn_rpn_sample", lib.frcnn_rpn_sample(
-                _p(self.anchor), cfg.H, cfg.W, cfg.A, _p(gt), B, G, _p(self.best_gt),
-                _p(self.flags), None, None, None, seed, image_base, cfg.rpn_batch, cfg.rpn_max_pos,
+                _p(self.anchor), cfg.H, cfg.W, cfg.A, _p(gt), B, G, _p(d["best_gt"]),
+                _p(d["flags"]), None, None, None, seed, image_base, cfg.rpn_batch, cfg.rpn_max_pos,
                 _p(r["label"]), _p(r["anchor"]), _p(r["gt"]), _p(r["gt_list"]), _p(r["pos"]),
                 _p(r["reg"]), _p(r["counts"]), ss))
         check("frcnn_topk", lib.frcnn_topk(
-            _p(score), B, N, cfg.pre_k, _p(self.anchor), _p(coord), _p(self.top_scores),
-            _p(self.top_idx), _p(self.cand), st))
+            _p(score), B, N, cfg.pre_k, _p(self.anchor), _p(coord), _p(d["top_scores"]),
+            _p(d["top_idx"]), _p(d["cand"]), ps))
         check("frcnn_nms", lib.frcnn_nms(
-            _p(self.cand), B, cfg.pre_k, cfg.nms_thr, cfg.post_n, _p(self.proposed),
-            _p(self.keep_pos), _p(self.keep_count), _p(self.nms_ws), self.nms_ws.numel(), st))
+            _p(d["cand"]), B, cfg.pre_k, cfg.nms_thr, cfg.post_n, _p(d["proposed"]),
+            _p(d["keep_pos"]), _p(d["keep_count"]), _p(d["nms_ws"]), d["nms_ws"].numel(), ps))
+        ev[1].record(prop)                             # proposals ready
+        if self.depth == 2:
+            main.wait_event(ev[1])
         if self.train:
-            self._ev[1].record(main)
-            self.side.wait_event(self._ev[1])          # proposals ready
+            self.side.wait_event(ev[1])
             ss = self.side.cuda_stream
             check("frcnn_label_proposals", lib.frcnn_label_proposals(
-                _p(self.proposed), _p(gt), _p(label), B, cfg.post_n, gt.shape[1], cfg.fg_thr,
-                cfg.iou_floor, cfg.bg_label, cfg.num_classes, _p(self.p_label), _p(self.gt_mask),
-                _p(self.gt_onehot), _p(self.gt_coord), _p(self.p_best), _p(self.p_iou), ss))
+                _p(d["proposed"]), _p(gt), _p(label), B, cfg.post_n, gt.shape[1], cfg.fg_thr,
+                cfg.iou_floor, cfg.bg_label, cfg.num_classes, _p(d["p_label"]), _p(d["gt_mask"]),
+                _p(d["gt_onehot"]), _p(d["gt_coord"]), _p(d["p_best"]), _p(d["p_iou"]), ss))
             check("frcnn_sample_proposals", lib.frcnn_sample_proposals(
-                _p(self.p_label), B, cfg.post_n, cfg.bg_label, None, None, None, seed, image_base,
-                cfg.head_batch, cfg.head_max_pos, _p(self.tindex), _p(self.head_counts), ss))
-            self._ev[2].record(self.side)
+                _p(d["p_label"]), B, cfg.post_n, cfg.bg_label, None, None, None, seed, image_base,
+                cfg.head_batch, cfg.head_max_pos, _p(d["tindex"]), _p(d["head_counts"]), ss))
+            ev[2].record(self.side)
         sb, sh, sw, sc = fmap.stride()
         if roi_events is not None:
             roi_events[0].record(main)
         check("frcnn_roi_crop_pool_fwd", lib.frcnn_roi_crop_pool_fwd(
-            _p(fmap), B, cfg.H, cfg.W, self.C, sb, sh, sw, sc, _p(self.proposed), cfg.post_n,
+            _p(fmap), B, cfg.H, cfg.W, self.C, sb, sh, sw, sc, _p(d["proposed"]), cfg.post_n,
             cfg.crop[0], cfg.crop[1], self.pool, _p(self.pooled), _p(self.winner), st))
         if roi_events is not None:
             roi_events[1].record(main)
         if self.train:
-            main.wait_event(self._ev[2])               # join: everything is ordered on `main` again
+            main.wait_event(ev[2])                     # join: everything is ordered on `main` again
+        ev[4].record(main)                             # this set may be rewritten after here
         return self
