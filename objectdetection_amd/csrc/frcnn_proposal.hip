@@ -188,36 +188,69 @@ nms_scan_kernel(const float4* __restrict__ boxes, const unsigned long long* __re
     if (tid == 0) s_cnt = count0;
     __syncthreads();
     const int nblk = min(NMS_CW, (K + 63) / 64 - cb0);
+    // Everything a column block needs from memory is independent of the scan's own results
+    // (the kept-tile words, the raw in-chunk words, the diagonal word, the box), so block
+    // jbl+1's loads are issued before block jbl is resolved and the serial part sees no load
+    // latency.  A wave owns kept tiles wave, wave+4, ... and in-chunk rows wave, wave+4, ...
+    struct Pre { unsigned long long hitk, diag, mdw[NMS_CW / 4]; float4 box; };
+    auto prefetch = [&](int jbl) {
+        Pre p;
+        const int col = jbl * 64 + lane;
+        p.diag = wave == 0 ? md[(size_t)jbl * NMS_COLS + col] : 0ull;
+        p.hitk = 0ull;
+#pragma unroll 4
+        for (int kt = wave; kt < nkt; kt += 4) p.hitk |= mk[(size_t)kt * NMS_COLS + col];
+#pragma unroll
+        for (int t = 0; t < NMS_CW / 4; ++t) {
+            const int ibl = wave + 4 * t;
+            p.mdw[t] = ibl < jbl ? md[(size_t)ibl * NMS_COLS + col] : 0ull;
+        }
+        const int j = (cb0 + jbl) * 64 + lane;
+        p.box = (wave == 0 && j < K) ? bx[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        return p;
+    };
+    Pre cur = prefetch(0);
 #pragma unroll 1
     for (int jbl = 0; jbl < nblk; ++jbl) {
         const int count = s_cnt;
         if (count >= post_n) break;                     // block-uniform
+        Pre nxt = cur;
+        if (jbl + 1 < nblk) nxt = prefetch(jbl + 1);    // block-uniform
         const int j0 = (cb0 + jbl) * 64;
-        const int col = jbl * 64 + lane;
-        const unsigned long long diag = wave == 0 ? md[(size_t)jbl * NMS_COLS + col] : 0ull;
-        unsigned long long hit = 0ull;
-#pragma unroll 4
-        for (int kt = wave; kt < nkt; kt += 4) hit |= mk[(size_t)kt * NMS_COLS + col];
-        for (int ibl = wave; ibl < jbl; ibl += 4) hit |= md[(size_t)ibl * NMS_COLS + col] & keptw[ibl];
+        unsigned long long hit = cur.hitk;
+#pragma unroll
+        for (int t = 0; t < NMS_CW / 4; ++t) {
+            const int ibl = wave + 4 * t;
+            if (ibl < jbl) hit |= cur.mdw[t] & keptw[ibl];
+        }
+        const unsigned long long diag = cur.diag;
         const unsigned long long dead = __ballot(hit != 0ull);
         if (lane == 0) deadw[wave] = dead;
         __syncthreads();
         if (wave == 0) {
             const int nvalid = K - j0 < 64 ? K - j0 : 64;
             const unsigned long long vmask = nvalid == 64 ? ~0ull : ((1ull << nvalid) - 1ull);
-            unsigned long long alive = uniform64(~(deadw[0] | deadw[1] | deadw[2] | deadw[3]) & vmask);
+            // Greedy order inside the block, resolved by relaxation instead of one kept box at
+            // a time: lane c's word `diag` lists the rows r < c that would suppress column c.
+            // A column whose suppressors are all dead is kept; one with a kept suppressor is
+            // dead; the lowest undecided column is always decidable, so the loop ends, and its
+            // fixed point is the greedy result.  Typical depth: a handful of rounds.
+            unsigned long long gone = uniform64((deadw[0] | deadw[1] | deadw[2] | deadw[3]) | ~vmask);
             unsigned long long keptmask = 0ull;
-            int room = post_n - count;
-            while (alive != 0ull && room > 0) {         // wave-uniform
-                const int r = __ffsll((long long)alive) - 1;
-                keptmask |= 1ull << r;
-                --room;
-                const unsigned long long sup = __ballot(((diag >> r) & 1ull) != 0ull);
-                alive &= ~(sup | (1ull << r));
+            const unsigned long long me = 1ull << lane;
+            while (~(gone | keptmask) != 0ull) {        // wave-uniform
+                const bool und = ((gone | keptmask) & me) == 0ull;
+                const unsigned long long k2 = __ballot(und && (diag & ~gone) == 0ull);
+                const unsigned long long g2 = __ballot(und && (diag & keptmask) != 0ull);
+                keptmask |= k2;
+                gone |= g2;
             }
+            // only the first `room` kept boxes fit
+            const int room = post_n - count;
+            keptmask = __ballot(((keptmask & me) != 0ull) && __popcll(keptmask & lanemask_lt()) < room);
             if ((keptmask >> lane) & 1ull) {
                 const int slot = count + __popcll(keptmask & lanemask_lt());
-                float4 v = bx[j0 + lane];
+                float4 v = cur.box;
                 v.x = clip01(v.x); v.y = clip01(v.y); v.z = clip01(v.z); v.w = clip01(v.w);
                 prop[slot] = v;
                 kidx[slot] = j0 + lane;
@@ -229,6 +262,7 @@ nms_scan_kernel(const float4* __restrict__ boxes, const unsigned long long* __re
             }
         }
         __syncthreads();
+        cur = nxt;
     }
     const int count = s_cnt;
     if (count >= post_n || last_chunk) {
