@@ -94,20 +94,29 @@ template <bool DIAG>
 __device__ __forceinline__ unsigned long long mask_tile(const NBox& a, float c1, const NBox* cols,
                                                         float thr, int lane) {
     unsigned long long mine = 0ull;
-#pragma unroll 8
-    for (int c = 0; c < 64; ++c) {
-        const NBox cb = cols[c];
-        const float iy0 = vmax2(a.y0, cb.y0), ix0 = vmax2(a.x0, cb.x0);
-        const float iy1 = vmin2(a.y1, cb.y1), ix1 = vmin2(a.x1, cb.x1);
-        const float inter = vmax2(iy1 - iy0, 0.0f) * vmax2(ix1 - ix0, 0.0f);
-        bool p = inter * c1 > a.t + cb.t;
-        if (DIAG) p = p && (c > lane);
-        if (__any(p)) {
-            const float u = a.area + cb.area - inter;
-            p = p && (a.area > 0.0f) && (cb.area > 0.0f) && (inter / u > thr);
+    // columns in groups of 8: the group's boxes are read from LDS up front, so the reads'
+    // latency overlaps the previous columns' arithmetic instead of preceding each column
+#pragma unroll 1
+    for (int c0 = 0; c0 < 64; c0 += 8) {
+        NBox grp[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) grp[u] = cols[c0 + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = c0 + u;
+            const NBox cb = grp[u];
+            const float iy0 = vmax2(a.y0, cb.y0), ix0 = vmax2(a.x0, cb.x0);
+            const float iy1 = vmin2(a.y1, cb.y1), ix1 = vmin2(a.x1, cb.x1);
+            const float inter = vmax2(iy1 - iy0, 0.0f) * vmax2(ix1 - ix0, 0.0f);
+            bool p = inter * c1 > a.t + cb.t;
+            if (DIAG) p = p && (c > lane);
+            if (__any(p)) {
+                const float u2 = a.area + cb.area - inter;
+                p = p && (a.area > 0.0f) && (cb.area > 0.0f) && (inter / u2 > thr);
+            }
+            const unsigned long long w = __ballot(p);
+            if (lane == c) mine = w;
         }
-        const unsigned long long w = __ballot(p);
-        if (lane == c) mine = w;
     }
     return mine;
 }
