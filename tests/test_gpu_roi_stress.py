@@ -1,0 +1,82 @@
+"""RoI crop + pool forward on adversarial box sets, against the C restatement of the oracle
+(bit-identical to the numpy oracle, tests/test_oracle_c.py): every walk of the staged kernel
+is exercised -- narrow boxes (two pooled-column groups per thread), wide boxes (one group per
+walk), boxes with samples exactly on feature rows / columns (rows listed twice), samples
+outside the image (general walk), flipped and degenerate boxes (direct path), several channel
+counts (one, two and three 64-channel slices per RoI).  Bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _boxes(rng, n, H, W):
+    out = []
+    for _ in range(n):
+        kind = rng.integers(0, 8)
+        y1, x1 = rng.random(2)
+        if kind == 0:                                   # tiny
+            h, w = rng.random(2) * 0.03
+        elif kind == 1:                                 # huge
+            y1, x1 = rng.random(2) * 0.1
+            h, w = 0.8 + rng.random(2) * 0.2
+        elif kind == 2:                                 # corners on grid lines: aligned samples
+            y1 = rng.integers(0, H - 1) / (H - 1); x1 = rng.integers(0, W - 1) / (W - 1)
+            h = rng.integers(1, H) / (H - 1); w = rng.integers(1, W) / (W - 1)
+        elif kind == 3:                                 # sticks out of the image
+            y1, x1 = rng.random(2) * 1.4 - 0.3
+            h, w = rng.random(2) * 0.8
+            out.append([y1, x1, y1 + h, x1 + w]); continue
+        elif kind == 4:                                 # wide and flat / tall and thin
+            h, w = (0.02, 0.9) if rng.random() < 0.5 else (0.9, 0.02)
+            y1, x1 = rng.random(2) * 0.08
+        elif kind == 5:                                 # degenerate or flipped
+            h, w = rng.choice([0.0, -0.2, 0.3], 2)
+        else:
+            h, w = rng.random(2) * 0.6
+        out.append([y1, x1, min(y1 + h, 1.0) if kind != 5 else y1 + h,
+                    min(x1 + w, 1.0) if kind != 5 else x1 + w])
+    return np.array(out, np.float32)
+
+
+@pytest.mark.parametrize("C,H,W", [(64, 31, 31), (128, 37, 62), (192, 20, 45), (512, 37, 62)])
+def test_roi_forward_stress(dev, C, H, W):
+    from objectdetection_amd import ops
+    lib = c_oracle.load()
+    rng = np.random.default_rng(C + H)
+    B, R = 2, 400
+    fm = (rng.standard_normal((B, H, W, C)) * 3).astype(np.float32)
+    rois = np.stack([_boxes(rng, R, H, W) for _ in range(B)])
+    rois[0, 0] = [0, 0, 1, 1]
+    rois[0, 1] = [np.nan, 0.1, 0.5, 0.6]
+    rois[0, 2] = [0.2, 0.2, 0.2, 0.2]
+    for pool, win in ((2, True), (2, False), (1, False)):
+        out, w = ops.roi_crop_pool_fwd(torch.tensor(fm, device=dev), torch.tensor(rois, device=dev),
+                                       (14, 14), pool, want_winner=win)
+        for b in range(B):
+            ro, rw = c_oracle.roi_crop_pool(lib, fm[b], rois[b], (14, 14), pool, want_winner=win)
+            got = out[b].cpu().numpy()
+            bad = np.argwhere(~((got == ro) | (np.isnan(got) & np.isnan(ro))))
+            assert len(bad) == 0, (pool, win, b, bad[:5], rois[b, bad[0][0]])
+            if win:
+                np.testing.assert_array_equal(w[b].cpu().numpy(), rw)
+
+
+def test_roi_forward_other_crop_sizes(dev):
+    """crop 16x16 / pool 2 (pooled width 8: two full column groups), 12x12 / pool 1 (three
+    groups), 7x7 / pool 1."""
+    from objectdetection_amd import ops
+    lib = c_oracle.load()
+    rng = np.random.default_rng(5)
+    H, W, C = 25, 40, 128
+    fm = rng.standard_normal((1, H, W, C)).astype(np.float32)
+    rois = _boxes(rng, 300, H, W)[None]
+    for crop, pool in (((16, 16), 2), ((12, 12), 1), ((7, 7), 1), ((14, 8), 2)):
+        out, _ = ops.roi_crop_pool_fwd(torch.tensor(fm, device=dev), torch.tensor(rois, device=dev),
+                                       crop, pool)
+        ro, _ = c_oracle.roi_crop_pool(lib, fm[0], rois[0], crop, pool, want_winner=False)
+        got = out[0].cpu().numpy()
+        assert ((got == ro) | (np.isnan(got) & np.isnan(ro))).all(), (crop, pool)
