@@ -43,3 +43,31 @@ def test_oracle_reproduces_golden(name):
         np.testing.assert_array_equal(pb[4], g["rpn_gt_list"][b])
         np.testing.assert_array_equal(pb[5], g["rpn_pos"][b])
         np.testing.assert_array_equal(pb[1], g["rpn_label"][b])
+
+
+def test_oracle_reproduces_next_rows_golden():
+    g = load("next_rows_small")
+    det = O.detect_postprocess(g["proposed"], g["cls_prob"], g["reg"], bg_label=20, max_out=30,
+                               iou_threshold=0.7, score_threshold=0.5)
+    np.testing.assert_array_equal(det["src"], g["det_src"])
+    np.testing.assert_array_equal(det["classes"], g["det_classes"])
+    np.testing.assert_array_equal(det["count"], g["det_count"])
+    np.testing.assert_allclose(det["boxes"], g["det_boxes"], rtol=1e-6, atol=1e-7)
+    rl, d_obj, d_reg = O.rpn_loss(g["pred_obj"], g["pred_reg"], g["pos"], g["label"], g["reg_gt"])
+    np.testing.assert_allclose(rl, g["rpn_loss"], rtol=1e-6)
+    np.testing.assert_allclose(d_obj, g["rpn_d_obj"], rtol=1e-5, atol=1e-10)
+    np.testing.assert_allclose(d_reg, g["rpn_d_reg"], rtol=1e-5, atol=1e-10)
+    B, R, K = g["cls_prob"].shape
+    hl, d_cls, d_reg2 = O.head_loss(g["cls_prob"], g["reg"].reshape(B, R, K, 4), g["tindex"],
+                                    g["onehot"], g["gt_mask"], g["gt_coord"])
+    np.testing.assert_allclose(hl, g["head_loss"], rtol=1e-6)
+    np.testing.assert_allclose(d_cls, g["head_d_cls"], rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(d_reg2, g["head_d_reg"], rtol=1e-5, atol=1e-10)
+    off = g["in_offsets"]
+    for b in range(len(off) - 1):
+        _, bb, ll = O.random_augmentation(None, g["in_labels"][off[b]:off[b + 1]],
+                                          g["in_boxes"][off[b]:off[b + 1]], int(g["G"]),
+                                          seed=int(g["seed"]), image_index=b)
+        np.testing.assert_array_equal(bb, g["aug_boxes"][b])
+        np.testing.assert_array_equal(ll, g["aug_labels"][b])
+        assert O.flip_decision(int(g["seed"]), b) == bool(g["flips"][b])

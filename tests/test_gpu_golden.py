@@ -45,3 +45,29 @@ def test_hip_path_matches_golden(dev, name):
     np.testing.assert_array_equal(lab["best_gt"].cpu().numpy(), g["best"])
     tindex, _ = ops.sample_proposals(lab["p_label"], seed=int(g["seed"]))
     np.testing.assert_array_equal(tindex.cpu().numpy(), g["tindex"])
+
+
+def test_next_rows_match_golden(dev):
+    """Detection post-process, loss assembly and input side against the frozen fixture."""
+    from objectdetection_amd import ops
+    g = np.load(os.path.join(GOLD, "next_rows_small.npz"), allow_pickle=False)
+    det = ops.detect_postprocess(T(g["proposed"], dev), T(g["cls_prob"], dev), T(g["reg"], dev),
+                                 bg_label=20, max_out=30, iou_threshold=0.7, score_threshold=0.5)
+    np.testing.assert_array_equal(det["count"].cpu().numpy(), g["det_count"])
+    np.testing.assert_array_equal(det["src"].cpu().numpy(), g["det_src"])
+    np.testing.assert_array_equal(det["classes"].cpu().numpy(), g["det_classes"])
+    np.testing.assert_allclose(det["boxes"].cpu().numpy(), g["det_boxes"], rtol=1e-5, atol=1e-7)
+    r = ops.rpn_loss(T(g["pred_obj"], dev), T(g["pred_reg"], dev), T(g["pos"], dev),
+                     T(g["label"], dev), T(g["reg_gt"], dev))
+    np.testing.assert_allclose(r["loss"].cpu().numpy(), g["rpn_loss"], rtol=1e-5)
+    np.testing.assert_allclose(r["d_obj"].cpu().numpy(), g["rpn_d_obj"], rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(r["d_reg"].cpu().numpy(), g["rpn_d_reg"], rtol=1e-5, atol=1e-9)
+    h = ops.head_loss(T(g["cls_prob"], dev), T(g["reg"], dev), T(g["tindex"], dev),
+                      T(g["onehot"], dev), T(g["gt_mask"], dev), T(g["gt_coord"], dev))
+    np.testing.assert_allclose(h["loss"].cpu().numpy(), g["head_loss"], rtol=1e-5)
+    np.testing.assert_allclose(h["d_cls"].cpu().numpy(), g["head_d_cls"], rtol=2e-5, atol=1e-8)
+    np.testing.assert_allclose(h["d_reg"].cpu().numpy(), g["head_d_reg"], rtol=1e-5, atol=1e-9)
+    gt, gl, _ = ops.pad_gt(T(g["in_boxes"], dev), T(g["in_labels"], dev), T(g["in_offsets"], dev),
+                           int(g["G"]), None, True, seed=int(g["seed"]))
+    np.testing.assert_array_equal(gt.cpu().numpy(), g["aug_boxes"])
+    np.testing.assert_array_equal(gl.cpu().numpy(), g["aug_labels"])
