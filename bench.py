@@ -148,6 +148,8 @@ def main():
     path = RegionProposalPath(cfg, B, C, device, train=not args.inference, depth=args.depth)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
+    ev_nms = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for _ in range(args.steps)]
 
     def sync():
         torch.cuda.synchronize(device)
@@ -163,7 +165,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         path.run(fmap, score, coord, gt, label, seed=100 + k, image_base=rank * B,
-                 roi_events=ev[k], inputs_ready=ready)
+                 roi_events=ev[k], inputs_ready=ready, nms_events=ev_nms[k])
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -174,6 +176,7 @@ def main():
 
     if rank == 0:
         roi_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        nms_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_nms]))
         alg = algorithmic_bytes_roi(cfg, C, B)
         achieved = alg / (roi_ms * 1e-3) / 1e9
         traffic = None
@@ -193,6 +196,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
+            "nms_us_per_image": nms_ms * 1e3 / B,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",

@@ -259,7 +259,10 @@ __device__ __forceinline__ AxisUnique axis_unique(float c1, float c2, int dim, i
     return u;
 }
 
-// wait until at most n (uniform) of this wave's vector memory operations are outstanding;
+// wait until at most n (uniform) of this wave's vector memory operations are outstanding.
+// Loads and stores of a wave retire in issue order on this counter (the compiler's own waits
+// rely on the same), so "at most n outstanding" means everything but the last n issued is done;
+// callers may under-count n (waits longer), never over-count;
 // n above 8 waits as for 8
 __device__ __forceinline__ void wait_vm_at_most(int n) {
     if (n < 4) {

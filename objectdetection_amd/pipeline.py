@@ -111,7 +111,8 @@ class RegionProposalPath:
 
     def run(self, fmap: torch.Tensor, score: torch.Tensor, coord: torch.Tensor,
             gt: Optional[torch.Tensor] = None, label: Optional[torch.Tensor] = None,
-            seed: int = 0, image_base: int = 0, roi_events=None, inputs_ready=None):
+            seed: int = 0, image_base: int = 0, roi_events=None, inputs_ready=None,
+            nms_events=None):
         """fmap [B,H,W,C] channels-last, score [B,H,W,A], coord [B,H,W,4A],
         gt [B,G,4], label [B,G] i64 (both only when train).  Returns self.
 
@@ -157,9 +158,13 @@ class RegionProposalPath:
         check("frcnn_topk", lib.frcnn_topk(
             _p(score), B, N, cfg.pre_k, _p(self.anchor), _p(coord), _p(d["top_scores"]),
             _p(d["top_idx"]), _p(d["cand"]), ps))
+        if nms_events is not None:
+            nms_events[0].record(prop)
         check("frcnn_nms", lib.frcnn_nms(
             _p(d["cand"]), B, cfg.pre_k, cfg.nms_thr, cfg.post_n, _p(d["proposed"]),
             _p(d["keep_pos"]), _p(d["keep_count"]), _p(d["nms_ws"]), d["nms_ws"].numel(), ps))
+        if nms_events is not None:
+            nms_events[1].record(prop)
         ev[1].record(prop)                             # proposals ready
         if self.depth == 2:
             main.wait_event(ev[1])
