@@ -65,6 +65,12 @@ topk_kernel(const float* __restrict__ scores, int N, int K, int n_pad,
 // instead of K^2/2; mask storage is two small per-image buffers reused by
 // every chunk.
 constexpr int NMS_CW = 16;                      // column blocks per chunk
+#ifndef NMS_SCAN_WAVES
+#define NMS_SCAN_WAVES 4                        // waves of the scan workgroup (1, 2 or 4)
+#endif
+#ifndef NMS_MASK_WAVES
+#define NMS_MASK_WAVES 4                        // row tiles (waves) per mask workgroup
+#endif
 constexpr int NMS_COLS = NMS_CW * 64;           // columns per chunk
 
 struct NBox { float y0, x0, y1, x1, area, t; };          // t = thr_lo * area
@@ -134,9 +140,10 @@ nms_mask_kernel(const float4* __restrict__ boxes, int K, int cb0, int KT, int po
     if (jb * 64 >= K || done[b]) return;                // block-uniform
     const int count = count_g[b];                       // boxes kept before this chunk
     const int nkt = (count + 63) >> 6;
-    const int rt0 = blockIdx.x * 4;
-    // tiles rt0..rt0+3: kept tiles are [0,nkt), in-chunk row blocks are KT + [0,jbl]
-    if (rt0 >= nkt && rt0 + 3 < KT) return;             // only empty kept tiles
+    const int nw = blockDim.x >> 6;                     // row tiles (waves) per workgroup
+    const int rt0 = blockIdx.x * nw;
+    // tiles rt0..rt0+nw-1: kept tiles are [0,nkt), in-chunk row blocks are KT + [0,jbl]
+    if (rt0 >= nkt && rt0 + nw - 1 < KT) return;        // only empty kept tiles
     if (rt0 > KT + jbl) return;                         // only tiles right of the diagonal
     __shared__ NBox s_col[64];
     const float4* bx = boxes + (size_t)b * K;
@@ -173,15 +180,15 @@ nms_mask_kernel(const float4* __restrict__ boxes, int K, int cb0, int KT, int po
     dst[jbl * 64 + lane] = mine;
 }
 
-// One workgroup (4 waves) per image walks the chunk's column blocks in order.
-__global__ void __launch_bounds__(256)
+// One workgroup (NMS_SCAN_WAVES waves) per image walks the chunk's column blocks in order.
+__global__ void __launch_bounds__(64 * NMS_SCAN_WAVES)
 nms_scan_kernel(const float4* __restrict__ boxes, const unsigned long long* __restrict__ maskK,
                 const unsigned long long* __restrict__ maskD, int K, int cb0, int KT, int post_n,
                 int last_chunk, int* __restrict__ count_g, int* __restrict__ done,
                 int32_t* __restrict__ keep_idx, float4* __restrict__ proposed,
                 int32_t* __restrict__ keep_pos, int32_t* __restrict__ keep_count) {
     __shared__ unsigned long long keptw[NMS_CW];        // keep bits of this chunk's blocks
-    __shared__ unsigned long long deadw[4];
+    __shared__ unsigned long long deadw[NMS_SCAN_WAVES];
     __shared__ int s_cnt;
     const int b = blockIdx.x;
     if (done[b]) return;                                // block-uniform
@@ -200,18 +207,19 @@ nms_scan_kernel(const float4* __restrict__ boxes, const unsigned long long* __re
     // Everything a column block needs from memory is independent of the scan's own results
     // (the kept-tile words, the raw in-chunk words, the diagonal word, the box), so block
     // jbl+1's loads are issued before block jbl is resolved and the serial part sees no load
-    // latency.  A wave owns kept tiles wave, wave+4, ... and in-chunk rows wave, wave+4, ...
-    struct Pre { unsigned long long hitk, diag, mdw[NMS_CW / 4]; float4 box; };
+    // latency.  A wave owns kept tiles wave, wave+SW, ... and in-chunk rows wave, wave+SW, ...
+    constexpr int SW = NMS_SCAN_WAVES;
+    struct Pre { unsigned long long hitk, diag, mdw[NMS_CW / SW]; float4 box; };
     auto prefetch = [&](int jbl) {
         Pre p;
         const int col = jbl * 64 + lane;
         p.diag = wave == 0 ? md[(size_t)jbl * NMS_COLS + col] : 0ull;
         p.hitk = 0ull;
 #pragma unroll 4
-        for (int kt = wave; kt < nkt; kt += 4) p.hitk |= mk[(size_t)kt * NMS_COLS + col];
+        for (int kt = wave; kt < nkt; kt += SW) p.hitk |= mk[(size_t)kt * NMS_COLS + col];
 #pragma unroll
-        for (int t = 0; t < NMS_CW / 4; ++t) {
-            const int ibl = wave + 4 * t;
+        for (int t = 0; t < NMS_CW / SW; ++t) {
+            const int ibl = wave + SW * t;
             p.mdw[t] = ibl < jbl ? md[(size_t)ibl * NMS_COLS + col] : 0ull;
         }
         const int j = (cb0 + jbl) * 64 + lane;
@@ -228,8 +236,8 @@ nms_scan_kernel(const float4* __restrict__ boxes, const unsigned long long* __re
         const int j0 = (cb0 + jbl) * 64;
         unsigned long long hit = cur.hitk;
 #pragma unroll
-        for (int t = 0; t < NMS_CW / 4; ++t) {
-            const int ibl = wave + 4 * t;
+        for (int t = 0; t < NMS_CW / SW; ++t) {
+            const int ibl = wave + SW * t;
             if (ibl < jbl) hit |= cur.mdw[t] & keptw[ibl];
         }
         const unsigned long long diag = cur.diag;
@@ -244,7 +252,10 @@ nms_scan_kernel(const float4* __restrict__ boxes, const unsigned long long* __re
             // A column whose suppressors are all dead is kept; one with a kept suppressor is
             // dead; the lowest undecided column is always decidable, so the loop ends, and its
             // fixed point is the greedy result.  Typical depth: a handful of rounds.
-            unsigned long long gone = uniform64((deadw[0] | deadw[1] | deadw[2] | deadw[3]) | ~vmask);
+            unsigned long long any_dead = 0ull;
+#pragma unroll
+            for (int w = 0; w < SW; ++w) any_dead |= deadw[w];
+            unsigned long long gone = uniform64(any_dead | ~vmask);
             unsigned long long keptmask = 0ull;
             const unsigned long long me = 1ull << lane;
             while (~(gone | keptmask) != 0ull) {        // wave-uniform
@@ -276,7 +287,7 @@ nms_scan_kernel(const float4* __restrict__ boxes, const unsigned long long* __re
     const int count = s_cnt;
     if (count >= post_n || last_chunk) {
         // zero padding (tf.image.combined_non_max_suppression pads boxes with 0)
-        for (int s = count + tid; s < post_n; s += 256) {
+        for (int s = count + tid; s < post_n; s += 64 * NMS_SCAN_WAVES) {
             prop[s] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (kp) kp[s] = -1;
         }
@@ -355,10 +366,11 @@ extern "C" int frcnn_nms(const float* boxes, int B, int K, float iou_threshold, 
     const float thr_lo = iou_threshold * 0.999996f;
     for (int cb0 = 0; cb0 < CB; cb0 += NMS_CW) {
         const int last = cb0 + NMS_CW >= CB;
-        FRCNN_LAUNCH(nms_mask_kernel, dim3((KT + NMS_CW + 3) / 4, NMS_CW, B), dim3(256), 0, st,
+        FRCNN_LAUNCH(nms_mask_kernel, dim3((KT + NMS_CW + NMS_MASK_WAVES - 1) / NMS_MASK_WAVES, NMS_CW, B),
+                     dim3(64 * NMS_MASK_WAVES), 0, st,
                      reinterpret_cast<const float4*>(boxes), K, cb0, KT, post_n, iou_threshold, c1,
                      thr_lo, done, count, keep_idx, maskK, maskD);
-        FRCNN_LAUNCH(nms_scan_kernel, dim3(B), dim3(256), 0, st,
+        FRCNN_LAUNCH(nms_scan_kernel, dim3(B), dim3(64 * NMS_SCAN_WAVES), 0, st,
                      reinterpret_cast<const float4*>(boxes), maskK, maskD, K, cb0, KT, post_n, last,
                      count, done, keep_idx, reinterpret_cast<float4*>(proposed), keep_pos,
                      keep_count);
