@@ -118,6 +118,7 @@ def main():
     ap.add_argument("--depth", type=int, default=2, choices=(1, 2),
                     help="batches in flight: 2 overlaps the proposals of batch i+1 with the RoI "
                          "kernel of batch i")
+    ap.add_argument("--topk", default="sort", choices=("sort", "lds"))
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend (gloo lets several ranks rehearse on one GPU)")
     args = ap.parse_args()
@@ -145,7 +146,8 @@ def main():
     cfg = workload_cfg()
     B, C = args.batch, args.channels
     fmap, score, coord, gt, label = make_inputs(cfg, B, C, device, seed=1000 + rank)
-    path = RegionProposalPath(cfg, B, C, device, train=not args.inference, depth=args.depth)
+    path = RegionProposalPath(cfg, B, C, device, train=not args.inference, depth=args.depth,
+                              topk=args.topk)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
     ev_nms = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))

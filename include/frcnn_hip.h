@@ -123,6 +123,16 @@ int frcnn_topk(const float* scores, int B, int N, int K,
                float* top_scores, int32_t* top_idx, float* cand_boxes,
                frcnn_stream_t stream);
 
+/* The same result by a stable radix sort through global memory, from small workgroups: any
+ * 1 <= K <= N, and it shares the chip with a concurrent bandwidth-bound kernel (frcnn_topk's
+ * workgroups need a CU to themselves).  workspace: frcnn_topk_sort_workspace_bytes(B,N)
+ * bytes (about 16 bytes per score), 256-byte aligned. */
+size_t frcnn_topk_sort_workspace_bytes(int B, int N);
+int frcnn_topk_sort(const float* scores, int B, int N, int K,
+                    const float* anchors, const float* deltas,
+                    float* top_scores, int32_t* top_idx, float* cand_boxes,
+                    void* workspace, size_t workspace_bytes, frcnn_stream_t stream);
+
 /* ---- a6 (second part): greedy NMS ------------------------------------------------
  * Replaces tf.image.combined_non_max_suppression(boxes, scores, post_n, post_n,
  * iou_threshold), Faster_RCNN/module/model.py:51 (= module/data.py:209), one

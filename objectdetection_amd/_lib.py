@@ -47,6 +47,8 @@ _SIGS = {
     "frcnn_encode": (_i, [_p, _p, _i64, _i, _p, _p]),
     "frcnn_decode_clip": (_i, [_p, _p, _i, _i64, _i, _p, _p]),
     "frcnn_topk": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
+    "frcnn_topk_sort_workspace_bytes": (_sz, [_i, _i]),
+    "frcnn_topk_sort": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "frcnn_nms_workspace_bytes": (_sz, [_i, _i, _i]),
     "frcnn_nms": (_i, [_p, _i, _i, _f, _i, _p, _p, _p, _p, _sz, _p]),
     "frcnn_roi_crop_pool_fwd": (_i, [_p, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _p, _i, _i, _i,

@@ -69,7 +69,9 @@ constexpr int NMS_CW = 16;                      // column blocks per chunk
 #define NMS_SCAN_WAVES 4                        // waves of the scan workgroup (1, 2 or 4)
 #endif
 #ifndef NMS_MASK_WAVES
-#define NMS_MASK_WAVES 4                        // row tiles (waves) per mask workgroup
+#define NMS_MASK_WAVES 1                        // row tiles (waves) per mask workgroup: one-wave
+                                                // workgroups also get wave slots while another
+                                                // stream's kernel fills the chip
 #endif
 constexpr int NMS_COLS = NMS_CW * 64;           // columns per chunk
 

@@ -151,9 +151,15 @@ def decode_clip(anchor_flat: torch.Tensor, deltas: torch.Tensor, clip_wh: bool) 
     return out
 
 
+def topk_sort_workspace_bytes(B: int, N: int) -> int:
+    return int(lib.frcnn_topk_sort_workspace_bytes(B, N))
+
+
 def topk(scores: torch.Tensor, k: int, anchor_flat: Optional[torch.Tensor] = None,
-         deltas: Optional[torch.Tensor] = None):
-    """scores [B,N] -> (values [B,k], idx [B,k] i32, cand_boxes [B,k,4] | None)."""
+         deltas: Optional[torch.Tensor] = None, method: str = "auto",
+         workspace: Optional[torch.Tensor] = None):
+    """scores [B,N] -> (values [B,k], idx [B,k] i32, cand_boxes [B,k,4] | None).
+    method: "lds" (frcnn_topk, k <= 16384), "sort" (frcnn_topk_sort, any k) or "auto"."""
     s = _cont(scores, "scores", torch.float32)
     if s.dim() != 2:
         raise ValueError("scores must be [B,N]")
@@ -167,9 +173,21 @@ def topk(scores: torch.Tensor, k: int, anchor_flat: Optional[torch.Tensor] = Non
         if a.shape[0] != N or d.shape[1] != N:
             raise ValueError("anchors / deltas do not match scores")
         cand = torch.empty((B, k, 4), dtype=torch.float32, device=s.device)
+    if method == "auto":
+        method = "lds" if k <= 16384 and workspace is None else "sort"
     with torch.cuda.device(s.device):
-        check("frcnn_topk", lib.frcnn_topk(_ptr(s), B, N, k, _ptr(a), _ptr(d), _ptr(vals),
-                                           _ptr(idx), _ptr(cand), _stream(s)))
+        if method == "lds":
+            check("frcnn_topk", lib.frcnn_topk(_ptr(s), B, N, k, _ptr(a), _ptr(d), _ptr(vals),
+                                               _ptr(idx), _ptr(cand), _stream(s)))
+        elif method == "sort":
+            need = topk_sort_workspace_bytes(B, N)
+            if workspace is None:
+                workspace = torch.empty(need, dtype=torch.uint8, device=s.device)
+            check("frcnn_topk_sort", lib.frcnn_topk_sort(
+                _ptr(s), B, N, k, _ptr(a), _ptr(d), _ptr(vals), _ptr(idx), _ptr(cand),
+                _ptr(workspace), workspace.numel() * workspace.element_size(), _stream(s)))
+        else:
+            raise ValueError("method must be 'auto', 'lds' or 'sort'")
     return vals, idx, cand
 
 

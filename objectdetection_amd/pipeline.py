@@ -44,9 +44,12 @@ def _p(t):
 class RegionProposalPath:
     def __init__(self, cfg: PathConfig = REFERENCE, batch: int = 1, channels: int = 512,
                  device="cuda", train: bool = True, want_winner: bool = False,
-                 fuse_pool: bool = True, depth: int = 1):
+                 fuse_pool: bool = True, depth: int = 1, topk: str = "sort"):
         if depth not in (1, 2):
             raise ValueError("depth must be 1 or 2")
+        if topk not in ("sort", "lds"):
+            raise ValueError("topk must be 'sort' (radix sort, small workgroups) or 'lds'")
+        self.topk = topk
         self.cfg, self.B, self.C = cfg, batch, channels
         self.device = torch.device(device)
         self.train, self.fuse_pool, self.depth = train, fuse_pool, depth
@@ -66,6 +69,7 @@ class RegionProposalPath:
         for _ in range(depth):
             d = dict(top_scores=e((B, K), f32), top_idx=e((B, K), i32), cand=e((B, K, 4), f32),
                      nms_ws=e((ops.nms_workspace_bytes(B, K, R),), u8),
+                     topk_ws=e((ops.topk_sort_workspace_bytes(B, N) if topk == "sort" else 1,), u8),
                      proposed=e((B, R, 4), f32), keep_pos=e((B, R), i32), keep_count=e((B,), i32),
                      ev=[torch.cuda.Event() for _ in range(5)])
             if train:
@@ -155,9 +159,14 @@ class RegionProposalPath:
                 _p(d["flags"]), None, None, None, seed, image_base, cfg.rpn_batch, cfg.rpn_max_pos,
                 _p(r["label"]), _p(r["anchor"]), _p(r["gt"]), _p(r["gt_list"]), _p(r["pos"]),
                 _p(r["reg"]), _p(r["counts"]), ss))
-        check("frcnn_topk", lib.frcnn_topk(
-            _p(score), B, N, cfg.pre_k, _p(self.anchor), _p(coord), _p(d["top_scores"]),
-            _p(d["top_idx"]), _p(d["cand"]), ps))
+        if self.topk == "sort":
+            check("frcnn_topk_sort", lib.frcnn_topk_sort(
+                _p(score), B, N, cfg.pre_k, _p(self.anchor), _p(coord), _p(d["top_scores"]),
+                _p(d["top_idx"]), _p(d["cand"]), _p(d["topk_ws"]), d["topk_ws"].numel(), ps))
+        else:
+            check("frcnn_topk", lib.frcnn_topk(
+                _p(score), B, N, cfg.pre_k, _p(self.anchor), _p(coord), _p(d["top_scores"]),
+                _p(d["top_idx"]), _p(d["cand"]), ps))
         if nms_events is not None:
             nms_events[0].record(prop)
         check("frcnn_nms", lib.frcnn_nms(

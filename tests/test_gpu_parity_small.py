@@ -92,7 +92,10 @@ def test_decode_close(dev, ref_inputs):
     np.testing.assert_allclose(got2, O.generate_coord(prop, t), rtol=1e-5, atol=1e-7)
 
 
-def test_topk_bit_exact_with_ties(dev, ref_inputs):
+@pytest.mark.parametrize("method", ["lds", "sort"])
+def test_topk_bit_exact_with_ties(dev, ref_inputs, method):
+    """Both top-k entry points: one workgroup per image in LDS, and the radix sort through
+    global memory."""
     from objectdetection_amd import ops
     s = ref_inputs["score"].reshape(2, -1).copy()
     s[0, 100:400] = 1.0            # saturated sigmoid ties
@@ -100,10 +103,33 @@ def test_topk_bit_exact_with_ties(dev, ref_inputs):
     s[1, 5] = -0.0
     s[1, 6] = 0.0
     for k in (1, 257, 6000, s.shape[1]):
-        v, i, _ = ops.topk(T(s, dev), k)
+        v, i, _ = ops.topk(T(s, dev), k, method=method)
         rv, ri = O.top_k(s, k)
         np.testing.assert_array_equal(i.cpu().numpy(), ri)
         np.testing.assert_array_equal(v.cpu().numpy(), rv)
+
+
+def test_topk_sort_large_and_negative(dev):
+    """Radix-sort top-k beyond the LDS kernel's K limit, scores of both signs, N not a
+    multiple of the block size, fused decode equal to the LDS kernel's."""
+    from objectdetection_amd import ops
+    rng = np.random.default_rng(4)
+    B, N = 3, 63001
+    s = rng.standard_normal((B, N)).astype(np.float32)
+    s[0, :5000] = np.float32(0.25)
+    s[2] = np.abs(s[2])
+    for k in (50000, N):
+        v, i, _ = ops.topk(T(s, dev), k, method="sort")
+        rv, ri = O.top_k(s, k)
+        np.testing.assert_array_equal(i.cpu().numpy(), ri)
+        np.testing.assert_array_equal(v.cpu().numpy(), rv)
+    anc = np.sort(rng.random((N, 2, 2)).astype(np.float32), axis=1).transpose(0, 2, 1).reshape(N, 4)
+    anc = np.ascontiguousarray(anc[:, [0, 2, 1, 3]])
+    dl = (rng.standard_normal((B, N, 4)) * 0.3).astype(np.float32)
+    a = ops.topk(T(s, dev), 12000, T(anc, dev), T(dl, dev), method="lds")
+    b = ops.topk(T(s, dev), 12000, T(anc, dev), T(dl, dev), method="sort")
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
 
 
 def test_proposals_bit_exact_given_boxes(dev, ref_inputs):
