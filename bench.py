@@ -191,6 +191,16 @@ def main():
             torch.cuda.synchronize(device)
             alone.append(e0.elapsed_time(e1))
         nms_ms = float(np.mean(alone[1:]))
+        # the RoI kernel alone (inside the step it shares the chip with the next batch's
+        # proposal stage)
+        roi_alone = []
+        for _ in range(4):
+            e0.record()
+            ops.roi_crop_pool_fwd(fmap, path.proposed, cfg.crop, cfg.pool, out=path.pooled)
+            e1.record()
+            torch.cuda.synchronize(device)
+            roi_alone.append(e0.elapsed_time(e1))
+        roi_alone_ms = float(np.mean(roi_alone[1:]))
         alg = algorithmic_bytes_roi(cfg, C, B)
         achieved = alg / (roi_ms * 1e-3) / 1e9
         traffic = None
@@ -234,6 +244,8 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "avg_launch_ms": roi_ms,
+                "avg_launch_ms_alone": roi_alone_ms,
+                "frac_alone": alg / (roi_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_launch": alg,
             },
         }
