@@ -36,7 +36,7 @@ anchors_kernel(float4* __restrict__ out, int H, int W, int A, AnchorHalf half) {
 // Tiled anchors x GT: the image's G boxes and areas sit in LDS; each thread
 // owns one anchor and walks the GT list (LDS broadcast reads), keeping the
 // first maximum.  Op order of module/data.py:82-96.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(FRCNN_TARGET_BLOCK > 256 ? FRCNN_TARGET_BLOCK : 256)
 iou_assign_kernel(const float4* __restrict__ anchors, int N, const float4* __restrict__ gt, int G,
                   float pos_thr, float neg_thr, float* __restrict__ max_iou,
                   int32_t* __restrict__ best_gt, uint8_t* __restrict__ flags,
@@ -140,7 +140,10 @@ extern "C" int frcnn_iou_assign(const float* anchors, int N, const float* gt, in
         return FRCNN_E_BADARG;
     if (G > 2048 || B > 65535) return FRCNN_E_UNSUPPORTED;
     const size_t lds = (size_t)G * 20;
-    FRCNN_LAUNCH(iou_assign_kernel, dim3((N + 255) / 256, B), dim3(256), lds,
+    // one-wave workgroups by default: they also get wave slots while another stream's kernel
+    // fills the chip (workgroups of several waves wait until that grid has drained)
+    FRCNN_LAUNCH(iou_assign_kernel, dim3((N + FRCNN_TARGET_BLOCK - 1) / FRCNN_TARGET_BLOCK, B),
+                 dim3(FRCNN_TARGET_BLOCK), lds,
                        (hipStream_t)stream, reinterpret_cast<const float4*>(anchors), N,
                        reinterpret_cast<const float4*>(gt), G, pos_thr, neg_thr, max_iou, best_gt,
                        flags, iou_full);

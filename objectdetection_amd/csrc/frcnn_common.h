@@ -9,6 +9,13 @@
 
 #define FRCNN_WAVE 64
 
+// Workgroup size of the training-target kernels (anchor assignment, both samplers, proposal
+// labels).  One wave: such workgroups take wave slots as they free up while a kernel of
+// another stream fills the chip; larger ones wait until that kernel's grid has drained.
+#ifndef FRCNN_TARGET_BLOCK
+#define FRCNN_TARGET_BLOCK 64
+#endif
+
 // hipGetLastError() also reports errors left behind by earlier, unrelated
 // runtime calls of this thread: clear it before a launch, read it after.
 #define FRCNN_LAUNCH(kernel, grid, block, lds, stream, ...)                         \

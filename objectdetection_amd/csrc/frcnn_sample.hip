@@ -6,7 +6,8 @@
 
 namespace frcnn {
 
-constexpr int SBLOCK = 1024;
+// threads of the one-workgroup-per-image sampling kernels (a multiple of 64, at most 1024)
+constexpr int SBLOCK = FRCNN_TARGET_BLOCK;
 constexpr int SMAX_BATCH = 1024;
 
 struct SampleShared {
@@ -255,7 +256,7 @@ sample_proposals_kernel(const long long* __restrict__ p_label, int R, int bg_lab
 // --------------------------------------------------------- proposal labelling ----
 // One thread per proposal; the image's GT boxes, areas and labels sit in LDS.
 // Op order of module/data.py:215-259.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(FRCNN_TARGET_BLOCK > 256 ? FRCNN_TARGET_BLOCK : 256)
 label_proposals_kernel(const float4* __restrict__ proposed, const float4* __restrict__ gt,
                        const long long* __restrict__ gt_label_in, int R, int G, float fg_thr,
                        float iou_floor, int bg_label, int num_classes,
@@ -372,7 +373,8 @@ extern "C" int frcnn_label_proposals(const float* proposed, const float* gt,
         return FRCNN_E_BADARG;
     if (G > 2048 || B > 65535) return FRCNN_E_UNSUPPORTED;
     const size_t lds = (size_t)G * (16 + 8 + 4);
-    FRCNN_LAUNCH(label_proposals_kernel, dim3((R + 255) / 256, B), dim3(256), lds,
+    FRCNN_LAUNCH(label_proposals_kernel, dim3((R + FRCNN_TARGET_BLOCK - 1) / FRCNN_TARGET_BLOCK, B),
+                 dim3(FRCNN_TARGET_BLOCK), lds,
                        (hipStream_t)stream, reinterpret_cast<const float4*>(proposed),
                        reinterpret_cast<const float4*>(gt),
                        reinterpret_cast<const long long*>(gt_label_in), R, G, fg_thr, iou_floor,
