@@ -1,13 +1,18 @@
 // Mini-batch sampling for the RPN (anchors) and for the head (proposals),
-// plus proposal <-> GT labelling.  One 1024-thread workgroup per image:
-// ordered ballot compaction, LDS radix select of the smallest shuffle keys,
-// LDS bitonic sort.  gfx950, wave64.  -ffp-contract=off.
+// plus proposal <-> GT labelling.  One workgroup per image: ordered ballot
+// compaction, LDS radix select of the smallest shuffle keys, LDS bitonic sort.
+// The workgroup is 1024 threads for small batches (shortest time for one image) and
+// one wave for large ones (a one-wave workgroup gets a wave slot while a
+// bandwidth-bound kernel of another stream fills the chip; larger ones wait for it).
+// gfx950, wave64.  -ffp-contract=off.
 #include "frcnn_common.h"
 
 namespace frcnn {
 
-// threads of the one-workgroup-per-image sampling kernels (a multiple of 64, at most 1024)
-constexpr int SBLOCK = FRCNN_TARGET_BLOCK;
+// threads of the one-workgroup-per-image sampling kernels: SBLOCK_BIG below
+// SBLOCK_SWITCH images, FRCNN_TARGET_BLOCK from there on
+constexpr int SBLOCK_BIG = 1024;
+constexpr int SBLOCK_SWITCH = 16;
 constexpr int SMAX_BATCH = 1024;
 
 struct SampleShared {
@@ -18,13 +23,13 @@ struct SampleShared {
     uint32_t order[SMAX_BATCH];            // final shuffle: order[r] = slot
     uint32_t hist[256];
     uint32_t sh[4];
-    uint32_t wcnt[3 * (SBLOCK / 64)];
+    uint32_t wcnt[3 * (SBLOCK_BIG / 64)];
     uint32_t ctr[2];
     int32_t tot[4];
 };
 
 // smallest `m` of key(0..M-1) by (key, position) -> s.sel[0..m) sorted ascending.
-template <typename KeyFn>
+template <int SBLOCK, typename KeyFn>
 __device__ void select_sorted(SampleShared& s, KeyFn key, int M, int m) {
     if (m <= 0) return;                    // block-uniform
     uint32_t T;
@@ -55,7 +60,7 @@ __device__ __forceinline__ int find_slot(const unsigned long long* inv, int lo, 
 // tf.where over the valid-anchor sub-list, module/data.py:108-110) else i.
 // On return (all threads): s.slot_item/slot_gt hold [positives | negatives] in
 // shuffled order, s.order the final permutation, s.tot = {P, Nneg, nop, status}.
-template <bool NEG_RANK, typename FlagFn, typename GtFn>
+template <int SBLOCK, bool NEG_RANK, typename FlagFn, typename GtFn>
 __device__ void sample_two_lists(SampleShared& s, FlagFn flag, GtFn pos_gt, int M, int neg_gt,
                                  const uint32_t* kp, const uint32_t* kn, const uint32_t* ka,
                                  uint64_t seed, uint32_t image, uint32_t stream_base, int batch,
@@ -88,7 +93,7 @@ __device__ void sample_two_lists(SampleShared& s, FlagFn flag, GtFn pos_gt, int 
     auto key_pos = [&](int i) -> uint32_t {
         return kp ? kp[i] : counter_key((uint32_t)i, stream_base + 0u, image, seed);
     };
-    select_sorted(s, key_pos, P, nop);
+    select_sorted<SBLOCK>(s, key_pos, P, nop);
     for (int t = tid; t < nop; t += SBLOCK)
         s.inv[t] = ((unsigned long long)(uint32_t)s.sel[t] << 32) | (uint32_t)t;
     __syncthreads();
@@ -96,7 +101,7 @@ __device__ void sample_two_lists(SampleShared& s, FlagFn flag, GtFn pos_gt, int 
     auto key_neg = [&](int i) -> uint32_t {
         return kn ? kn[i] : counter_key((uint32_t)i, stream_base + 1u, image, seed);
     };
-    select_sorted(s, key_neg, Nn, non);
+    select_sorted<SBLOCK>(s, key_neg, Nn, non);
     for (int t = tid; t < non; t += SBLOCK)
         s.inv[nop + t] = ((unsigned long long)(uint32_t)s.sel[t] << 32) | (uint32_t)(nop + t);
     __syncthreads();
@@ -175,6 +180,7 @@ __device__ void sample_two_lists(SampleShared& s, FlagFn flag, GtFn pos_gt, int 
 }
 
 // ---------------------------------------------------------------- RPN sampler ----
+template <int SBLOCK>
 __global__ void __launch_bounds__(SBLOCK)
 rpn_sample_kernel(const float4* __restrict__ anchors, int N, int W, int A,
                   const float4* __restrict__ gt, int G, const int32_t* __restrict__ best_gt,
@@ -195,7 +201,7 @@ rpn_sample_kernel(const float4* __restrict__ anchors, int N, int W, int A,
                ((f & FRCNN_F_VALID) ? 4u : 0u);
     };
     auto pos_gt = [&](int i) -> int { return bg[i]; };
-    sample_two_lists<true>(s, flag, pos_gt, N, G - 1,
+    sample_two_lists<SBLOCK, true>(s, flag, pos_gt, N, G - 1,
                            keys_pos ? keys_pos + (size_t)b * N : nullptr,
                            keys_neg ? keys_neg + (size_t)b * N : nullptr,
                            keys_all ? keys_all + (size_t)b * batch : nullptr, seed,
@@ -230,6 +236,7 @@ rpn_sample_kernel(const float4* __restrict__ anchors, int N, int W, int A,
 }
 
 // --------------------------------------------------------------- head sampler ----
+template <int SBLOCK>
 __global__ void __launch_bounds__(SBLOCK)
 sample_proposals_kernel(const long long* __restrict__ p_label, int R, int bg_label,
                         const uint32_t* __restrict__ keys_pos, const uint32_t* __restrict__ keys_neg,
@@ -241,7 +248,7 @@ sample_proposals_kernel(const long long* __restrict__ p_label, int R, int bg_lab
     const long long* pl = p_label + (size_t)b * R;
     auto flag = [&](int i) -> uint32_t { return pl[i] != (long long)bg_label ? 1u : 2u; };
     auto pos_gt = [&](int) -> int { return 0; };
-    sample_two_lists<false>(s, flag, pos_gt, R, 0,
+    sample_two_lists<SBLOCK, false>(s, flag, pos_gt, R, 0,
                             keys_pos ? keys_pos + (size_t)b * R : nullptr,
                             keys_neg ? keys_neg + (size_t)b * R : nullptr,
                             keys_all ? keys_all + (size_t)b * batch : nullptr, seed,
@@ -333,13 +340,16 @@ extern "C" int frcnn_rpn_sample(const float* anchors, int H, int W, int A, const
     if (any && !all) return FRCNN_E_BADARG;
     const long long N = (long long)H * W * A;
     if (N > (1ll << 24) || batch > SMAX_BATCH) return FRCNN_E_UNSUPPORTED;
-    FRCNN_LAUNCH(rpn_sample_kernel, dim3(B), dim3(SBLOCK), 0, (hipStream_t)stream,
-                       reinterpret_cast<const float4*>(anchors), (int)N, W, A,
-                       reinterpret_cast<const float4*>(gt), G, best_gt, flags, keys_pos, keys_neg,
-                       keys_all, seed, image_base, batch, max_pos, batch_label,
-                       reinterpret_cast<float4*>(batch_anchor), reinterpret_cast<float4*>(batch_gt),
-                       reinterpret_cast<long long*>(gt_list), reinterpret_cast<long long*>(batch_pos),
-                       reinterpret_cast<float4*>(batch_reg_gt), counts);
+#define FRCNN_RPN_SAMPLE(BLK)                                                                    \
+    FRCNN_LAUNCH(rpn_sample_kernel<BLK>, dim3(B), dim3(BLK), 0, (hipStream_t)stream,             \
+                 reinterpret_cast<const float4*>(anchors), (int)N, W, A,                         \
+                 reinterpret_cast<const float4*>(gt), G, best_gt, flags, keys_pos, keys_neg,     \
+                 keys_all, seed, image_base, batch, max_pos, batch_label,                        \
+                 reinterpret_cast<float4*>(batch_anchor), reinterpret_cast<float4*>(batch_gt),   \
+                 reinterpret_cast<long long*>(gt_list), reinterpret_cast<long long*>(batch_pos), \
+                 reinterpret_cast<float4*>(batch_reg_gt), counts)
+    if (B < SBLOCK_SWITCH) FRCNN_RPN_SAMPLE(SBLOCK_BIG); else FRCNN_RPN_SAMPLE(FRCNN_TARGET_BLOCK);
+#undef FRCNN_RPN_SAMPLE
     return FRCNN_OK;
 }
 
@@ -355,10 +365,13 @@ extern "C" int frcnn_sample_proposals(const int64_t* p_label, int B, int R, int 
     const bool all = keys_pos && keys_neg && keys_all;
     if (any && !all) return FRCNN_E_BADARG;
     if (R > (1 << 24) || batch > SMAX_BATCH) return FRCNN_E_UNSUPPORTED;
-    FRCNN_LAUNCH(sample_proposals_kernel, dim3(B), dim3(SBLOCK), 0, (hipStream_t)stream,
-                       reinterpret_cast<const long long*>(p_label), R, bg_label, keys_pos, keys_neg,
-                       keys_all, seed, image_base, batch, max_pos,
-                       reinterpret_cast<long long*>(tindex), counts);
+#define FRCNN_HEAD_SAMPLE(BLK)                                                                   \
+    FRCNN_LAUNCH(sample_proposals_kernel<BLK>, dim3(B), dim3(BLK), 0, (hipStream_t)stream,       \
+                 reinterpret_cast<const long long*>(p_label), R, bg_label, keys_pos, keys_neg,   \
+                 keys_all, seed, image_base, batch, max_pos,                                     \
+                 reinterpret_cast<long long*>(tindex), counts)
+    if (B < SBLOCK_SWITCH) FRCNN_HEAD_SAMPLE(SBLOCK_BIG); else FRCNN_HEAD_SAMPLE(FRCNN_TARGET_BLOCK);
+#undef FRCNN_HEAD_SAMPLE
     return FRCNN_OK;
 }
 

@@ -23,16 +23,13 @@ def nms_properties(boxes, keep, count, thr, post_n):
     k = keep[:n].astype(np.int64)
     assert (np.diff(k) > 0).all(), "keep positions ascending"
     kb = boxes[k]
-    # kept boxes do not suppress each other
-    for i in range(0, n, 256):
-        iou = np.stack([O.nms_iou(kb[j], kb[:j]) if j else np.zeros(0, np.float32)
-                        for j in range(i, min(n, i + 8))], 0) if False else None
+    # kept boxes do not suppress each other (first 400 of them)
     sub = kb[: min(n, 400)]
     for j in range(1, sub.shape[0]):
         assert not (O.nms_iou(sub[j], sub[:j]) > np.float32(thr)).any()
     # every skipped candidate before the last kept one is suppressed by an earlier kept box
     if n:
-        last = int(k[-1]) if n < post_n else int(k[-1])
+        last = int(k[-1])
         skipped = np.setdiff1d(np.arange(last), k)[:300]
         for s in skipped:
             earlier = kb[k < s]

@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""Times the hot path on each benchmark configuration (HIP events, one GPU) and writes one
+JSON object: B=1 latency of the 600x1000 workload with its stages, the ship configuration at
+batch 16, the 100,000-candidate NMS and the G=200 anchor assignment of the dense
+configuration, and a training step's RoI part (forward with winner + backward) at batch 8.
+
+  python tools/config_table.py [out.json]
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from objectdetection_amd import ops  # noqa: E402
+from objectdetection_amd.config import PathConfig  # noqa: E402
+from objectdetection_amd.pipeline import RegionProposalPath  # noqa: E402
+
+dev = torch.device("cuda:0")
+
+
+def timed(fn, reps=10, warm=2):
+    """Mean and minimum HIP-event time of fn() in ms."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return dict(mean_ms=float(np.mean(ts)), min_ms=float(np.min(ts)))
+
+
+def path_times(cfg, B, C, train, seed):
+    fmap, score, coord, gt, label = bench.make_inputs(cfg, B, C, dev, seed)
+    path = RegionProposalPath(cfg, B, C, dev, train=train, depth=1)
+    run = (lambda: path.run(fmap, score, coord, gt, label, seed=1)) if train else \
+          (lambda: path.run(fmap, score, coord))
+    out = dict(whole_path=timed(run))
+    ws = path.topk_ws
+    out["topk_sort"] = timed(lambda: ops.topk(score.reshape(B, -1), cfg.pre_k, anchor_flat=path.anchor.reshape(-1, 4),
+                                              deltas=coord.reshape(B, -1, 4), method="sort",
+                                              workspace=ws))
+    out["nms"] = timed(lambda: ops.nms(path.cand, cfg.nms_thr, cfg.post_n, workspace=path.nms_ws))
+    out["roi_fwd"] = timed(lambda: ops.roi_crop_pool_fwd(fmap, path.proposed, cfg.crop, cfg.pool,
+                                                         out=path.pooled))
+    if train:
+        out["iou_assign"] = timed(lambda: ops.iou_assign(path.anchor.reshape(-1, 4), gt))
+    out["images_per_s"] = B / (out["whole_path"]["mean_ms"] * 1e-3)
+    out["mean_kept_proposals"] = float(path.keep_count.float().mean().item())
+    return out
+
+
+def main():
+    res = {}
+    cfg1 = bench.workload_cfg()
+    res["config1_600x1000_B1_train"] = path_times(cfg1, 1, 512, True, 1000)
+    res["config1_600x1000_B1_inference"] = path_times(cfg1, 1, 512, False, 1000)
+
+    ship = PathConfig(H=48, W=48, scales=(32, 64, 128, 256), base_w=500.0, base_h=500.0, G=50,
+                      pre_k=6000, post_n=1500)
+    res["config2_ship_768x768_B16_train"] = path_times(ship, 16, 512, True, 2000)
+
+    # dense stress: NMS over 100,000 candidates -> 2,000; anchors x 200 GT
+    rng = np.random.default_rng(303)
+    K = 100_000
+    cy, cx = rng.uniform(0, 1, K), rng.uniform(0, 1, K)
+    h = np.exp(rng.uniform(np.log(0.01), np.log(0.3), K))
+    w = np.exp(rng.uniform(np.log(0.01), np.log(0.3), K))
+    boxes = np.clip(np.stack([cy - h / 2, cx - w / 2, cy + h / 2, cx + w / 2], 1), 0, 1)
+    boxes = torch.from_numpy(boxes.astype(np.float32)[None]).to(dev)
+    nws = torch.empty((ops.nms_workspace_bytes(1, K, 2000),), dtype=torch.uint8, device=dev)
+    res["config3_nms_100k_to_2000"] = timed(lambda: ops.nms(boxes, 0.7, 2000, workspace=nws))
+    _, _, cnt = ops.nms(boxes, 0.7, 2000, workspace=nws)
+    res["config3_nms_100k_to_2000"]["kept"] = int(cnt[0])
+    a3 = ops.anchors(50, 83, (64, 128, 256, 384, 512), (0.5, 1, 2), 1333.0, 800.0, dev)
+    g3 = torch.rand((1, 200, 2), device=dev) * 0.7
+    gt3 = torch.cat([g3, g3 + 0.05 + torch.rand((1, 200, 2), device=dev) * 0.25], -1).clamp(0, 1)
+    res["config3_iou_assign_62250x200"] = timed(lambda: ops.iou_assign(a3.reshape(-1, 4), gt3))
+
+    # training step, RoI part: forward with winner index + backward, batch 8
+    B = 8
+    fmap, score, coord, gt, label = bench.make_inputs(cfg1, B, 512, dev, 3000)
+    path = RegionProposalPath(cfg1, B, 512, dev, train=True, want_winner=True, depth=1)
+    path.run(fmap, score, coord, gt, label, seed=1)
+    dY = torch.randn_like(path.pooled)
+    res["config5_B8_path_forward_with_winner"] = timed(
+        lambda: path.run(fmap, score, coord, gt, label, seed=1), reps=5)
+    res["config5_B8_roi_backward"] = timed(
+        lambda: ops.roi_crop_pool_bwd(dY, path.winner, path.proposed, tuple(fmap.shape),
+                                      cfg1.crop, cfg1.pool), reps=3, warm=1)
+    txt = json.dumps(res, indent=1)
+    print(txt)
+    if len(sys.argv) > 1:
+        with open(sys.argv[1], "w") as fh:
+            fh.write(txt + "\n")
+
+
+if __name__ == "__main__":
+    main()

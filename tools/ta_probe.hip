@@ -20,6 +20,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // mode 6: LDS ds_read_b128, all lanes, conflict-free
 // mode 7: direct-to-LDS 16-byte loads (1 KiB per wave instruction), 4 x 256 B segments
 // mode 8: register load + ds_write_b128 of the same data
+// mode 9: 4-byte loads, all lanes, one 256 B segment     mode 10: 8-byte loads, 2 x 256 B
+// mode 11: direct-to-LDS 4-byte loads (256 B per wave instruction)
 template <int MODE>
 __global__ void __launch_bounds__(256) probe(const float* __restrict__ src, int cells, int iters,
                                              float* __restrict__ sink) {
@@ -58,6 +60,20 @@ __global__ void __launch_bounds__(256) probe(const float* __restrict__ src, int 
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(
                         rs, (__attribute__((address_space(3))) void*)&lds[(w * 8 + u) * 64], 16, voff, soff, 0, 0);
                     v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                } else if (MODE == 9) {
+                    uint32_t soff = c * 2048u;
+                    v[u] = (f32x4){__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (uint32_t)lane * 4u, soff, 0)), 0.f, 0.f, 0.f};
+                } else if (MODE == 10) {
+                    uint32_t soff = c * 2048u;
+                    if (c + 9 >= (uint32_t)cells) soff = 0;
+                    const auto t = __builtin_amdgcn_raw_buffer_load_b64(rs, (uint32_t)(lane >> 5) * 2048u * 3u + (uint32_t)(lane & 31) * 8u, soff, 0);
+                    v[u] = (f32x4){__builtin_bit_cast(float, t[0]), __builtin_bit_cast(float, t[1]), 0.f, 0.f};
+                } else if (MODE == 11) {
+                    uint32_t soff = c * 2048u;
+                    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        rs, (__attribute__((address_space(3))) void*)&lds[(w * 8 + u) * 64], 4, (uint32_t)lane * 4u, soff, 0, 0);
+                    v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 } else if (MODE == 8) {
                     uint32_t soff = c * 2048u;
                     if (c + 9 >= (uint32_t)cells) soff = 0;
@@ -78,7 +94,7 @@ __global__ void __launch_bounds__(256) probe(const float* __restrict__ src, int 
             cell = (cell + 41u) % (uint32_t)cells;
         }
     }
-    if (MODE == 7 || MODE == 8) {
+    if (MODE == 7 || MODE == 8 || MODE == 11) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         acc += lds[threadIdx.x];
     }
@@ -120,5 +136,8 @@ int main() {
     run<6>("LDS ds_read_b128 all lanes", src, cells, sink, 64);
     run<7>("direct-to-LDS dwordx4, 4 x 256 B segments", src, cells, sink, 64);
     run<8>("register load + ds_write_b128", src, cells, sink, 64);
+    run<9>("4-byte loads, all lanes, 256 B", src, cells, sink, 16);
+    run<10>("8-byte loads, all lanes, 2 x 256 B", src, cells, sink, 32);
+    run<11>("direct-to-LDS 4-byte loads, 256 B", src, cells, sink, 16);
     return 0;
 }
