@@ -61,3 +61,17 @@ def test_no_product_module_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dp, f)).read()
                 assert "oracle" not in src, f"{f} mentions the oracle"
+
+
+def test_library_is_not_older_than_its_sources():
+    """The in-tree library is what the GPU tests load: a source edited (or reverted) after the
+    last build would be tested through a stale binary."""
+    import glob
+    import os
+    from objectdetection_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    srcs = glob.glob(os.path.join(root, "objectdetection_amd", "csrc", "*.hip")) + \
+        glob.glob(os.path.join(root, "objectdetection_amd", "csrc", "*.h")) + \
+        glob.glob(os.path.join(root, "include", "*.h"))
+    newest = max(os.path.getmtime(f) for f in srcs)
+    assert os.path.getmtime(_lib.LIB_PATH) >= newest, "run `make -C objectdetection_amd/csrc`"
