@@ -259,9 +259,25 @@ head_loss_finish_kernel(const float* __restrict__ cls_prob, const float* __restr
     }
 }
 
+// Zero fill as a kernel of this library (a memset node recorded into a HIP graph was seen to
+// lose its place in the order on ROCm 7.2; a kernel keeps stream order under capture).
+template <typename T>
+__global__ void __launch_bounds__(256) zero_fill_kernel(T* __restrict__ p, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = T{};
+}
+
 }  // namespace frcnn
 
 using namespace frcnn;
+
+template <typename T>
+static int zero_fill(T* p, size_t n, hipStream_t st) {
+    if (!p || n == 0) return FRCNN_OK;
+    const size_t want = (n + 255) / 256;
+    FRCNN_LAUNCH(zero_fill_kernel<T>, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, st, p, n);
+    return FRCNN_OK;
+}
 
 extern "C" int frcnn_rpn_loss(const float* pred_obj, const float* pred_reg, const int64_t* pos,
                               const float* label, const float* reg_gt, int B, int H, int W, int A,
@@ -275,8 +291,9 @@ extern "C" int frcnn_rpn_loss(const float* pred_obj, const float* pred_reg, cons
         return FRCNN_E_BADARG;
     const int N = H * W * A;
     hipStream_t st = (hipStream_t)stream;
-    if (d_obj && hipMemsetAsync(d_obj, 0, (size_t)B * N * 4, st) != hipSuccess) return FRCNN_E_LAUNCH;
-    if (d_reg && hipMemsetAsync(d_reg, 0, (size_t)B * N * 16, st) != hipSuccess) return FRCNN_E_LAUNCH;
+    if (zero_fill(d_obj, (size_t)B * N, st) != FRCNN_OK ||
+        zero_fill(reinterpret_cast<float4*>(d_reg), (size_t)B * N, st) != FRCNN_OK)
+        return FRCNN_E_LAUNCH;
     FRCNN_LAUNCH(rpn_loss_partial_kernel, dim3(B), dim3(LOSS_BLOCK), 0, st, pred_obj, pred_reg, pos,
                  label, reg_gt, N, S, H, W, A, partial);
     FRCNN_LAUNCH(rpn_loss_finish_kernel, dim3(B), dim3(LOSS_BLOCK), 0, st, pred_obj, pred_reg, pos,
@@ -296,8 +313,9 @@ extern "C" int frcnn_head_loss(const float* cls_prob, const float* reg, const in
          reinterpret_cast<uintptr_t>(d_reg)) & 15u)
         return FRCNN_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
-    if (d_cls && hipMemsetAsync(d_cls, 0, (size_t)B * R * K * 4, st) != hipSuccess) return FRCNN_E_LAUNCH;
-    if (d_reg && hipMemsetAsync(d_reg, 0, (size_t)B * R * K * 16, st) != hipSuccess) return FRCNN_E_LAUNCH;
+    if (zero_fill(d_cls, (size_t)B * R * K, st) != FRCNN_OK ||
+        zero_fill(reinterpret_cast<float4*>(d_reg), (size_t)B * R * K, st) != FRCNN_OK)
+        return FRCNN_E_LAUNCH;
     FRCNN_LAUNCH(head_loss_partial_kernel, dim3(B), dim3(LOSS_BLOCK), 0, st, cls_prob, reg, tindex,
                  label, gt_mask, gt_coord, R, S, K, partial);
     FRCNN_LAUNCH(head_loss_finish_kernel, dim3(B), dim3(LOSS_BLOCK), 0, st, cls_prob, reg, tindex,

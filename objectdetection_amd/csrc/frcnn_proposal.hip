@@ -139,8 +139,10 @@ nms_mask_kernel(const float4* __restrict__ boxes, int K, int cb0, int KT, int po
     const int b = blockIdx.z;
     const int jbl = blockIdx.y;                         // column block inside the chunk
     const int jb = cb0 + jbl;
-    if (jb * 64 >= K || done[b]) return;                // block-uniform
-    const int count = count_g[b];                       // boxes kept before this chunk
+    // the first chunk starts from an empty keep list and never reads count / done: the
+    // workspace needs no clearing between calls
+    if (jb * 64 >= K || (cb0 != 0 && done[b])) return;  // block-uniform
+    const int count = cb0 != 0 ? count_g[b] : 0;        // boxes kept before this chunk
     const int nkt = (count + 63) >> 6;
     const int nw = blockDim.x >> 6;                     // row tiles (waves) per workgroup
     const int rt0 = blockIdx.x * nw;
@@ -193,7 +195,7 @@ nms_scan_kernel(const float4* __restrict__ boxes, const unsigned long long* __re
     __shared__ unsigned long long deadw[NMS_SCAN_WAVES];
     __shared__ int s_cnt;
     const int b = blockIdx.x;
-    if (done[b]) return;                                // block-uniform
+    if (cb0 != 0 && done[b]) return;                    // block-uniform
     const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
     const float4* bx = boxes + (size_t)b * K;
     const unsigned long long* mk = maskK + (size_t)b * KT * NMS_COLS;
@@ -201,7 +203,7 @@ nms_scan_kernel(const float4* __restrict__ boxes, const unsigned long long* __re
     float4* prop = proposed + (size_t)b * post_n;
     int32_t* kidx = keep_idx + (size_t)b * post_n;
     int32_t* kp = keep_pos ? keep_pos + (size_t)b * post_n : nullptr;
-    const int count0 = count_g[b];
+    const int count0 = cb0 != 0 ? count_g[b] : 0;
     const int nkt = (count0 + 63) >> 6;
     if (tid == 0) s_cnt = count0;
     __syncthreads();
@@ -287,18 +289,19 @@ nms_scan_kernel(const float4* __restrict__ boxes, const unsigned long long* __re
         cur = nxt;
     }
     const int count = s_cnt;
-    if (count >= post_n || last_chunk) {
+    const bool finished = count >= post_n || last_chunk;
+    if (finished) {
         // zero padding (tf.image.combined_non_max_suppression pads boxes with 0)
         for (int s = count + tid; s < post_n; s += 64 * NMS_SCAN_WAVES) {
             prop[s] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (kp) kp[s] = -1;
         }
-        if (tid == 0) {
-            done[b] = 1;
-            if (keep_count) keep_count[b] = count;
-        }
+        if (tid == 0 && keep_count) keep_count[b] = count;
     }
-    if (tid == 0) count_g[b] = count;
+    if (tid == 0) {
+        done[b] = finished ? 1 : 0;
+        count_g[b] = count;
+    }
 }
 
 }  // namespace frcnn
@@ -362,7 +365,6 @@ extern "C" int frcnn_nms(const float* boxes, int B, int K, float iou_threshold, 
     ws += align256((size_t)B * post_n * 4);
     int* count = reinterpret_cast<int*>(ws);
     int* done = count + B;
-    if (hipMemsetAsync(count, 0, (size_t)B * 8, st) != hipSuccess) return FRCNN_E_LAUNCH;
     // filter constants: iou > thr  =>  inter*(1+thr) > thr*(1-4e-6)*(area_i+area_j)
     const float c1 = 1.0f + iou_threshold;
     const float thr_lo = iou_threshold * 0.999996f;

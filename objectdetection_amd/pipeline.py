@@ -92,6 +92,29 @@ class RegionProposalPath:
             if k != "ev":
                 setattr(self, k, v)
 
+    def capture(self, fmap, score, coord, gt=None, label=None, seed: int = 0,
+                image_base: int = 0):
+        """Records one run() over these tensors into a HIP graph and returns it.
+
+        `graph.replay()` then re-issues the whole path (some 45 kernel launches) with one
+        host call: for a single image the path is launch-bound, and the replay is what a
+        serving loop would call.  The tensors are read in place at every replay (copy new
+        inputs into them); results land in the same buffers as after run().  Scalars are
+        launch arguments, so a replay repeats `seed`: meant for inference, or for training
+        targets that may repeat their sampling.  Needs depth == 1."""
+        if self.depth != 1:
+            raise ValueError("capture() records one batch at a time: build the path with depth=1")
+        warm = torch.cuda.Stream(self.device)
+        warm.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(warm):                      # first launches load the code objects
+            self.run(fmap, score, coord, gt, label, seed=seed, image_base=image_base)
+        torch.cuda.current_stream(self.device).wait_stream(warm)
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self.run(fmap, score, coord, gt, label, seed=seed, image_base=image_base)
+        return graph
+
     def _validate(self, fmap, score, coord, gt, label):
         cfg, B = self.cfg, self.B
 

@@ -44,3 +44,37 @@ def test_depth2_equals_depth1(dev):
     for w, h in zip(want, got):
         for k in w:
             assert torch.equal(w[k], h[k]), k
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_graph_replay_equals_run(dev, train):
+    """The path recorded into a HIP graph: a replay on new contents of the input tensors gives
+    what run() gives on them (the training variant forks to and joins the side stream inside
+    the capture)."""
+    from objectdetection_amd.config import PathConfig
+    from objectdetection_amd.pipeline import RegionProposalPath
+    g = np.load(os.path.join(GOLD, "ref_small.npz"), allow_pickle=False)
+    cfg = PathConfig(H=int(g["H"]), W=int(g["W"]), scales=tuple(g["scales"].tolist()),
+                     G=int(g["G"]), pre_k=int(g["pre_k"]), post_n=int(g["post_n"]))
+    B, C = g["gt"].shape[0], int(g["C"])
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(11)
+    gt, label = torch.from_numpy(g["gt"]).to(dev), torch.from_numpy(g["label"]).to(dev)
+    fmap = torch.rand((B, cfg.H, cfg.W, C), generator=gen, device=dev)
+    score = torch.rand((B, cfg.H, cfg.W, cfg.A), generator=gen, device=dev)
+    coord = torch.randn((B, cfg.H, cfg.W, 4 * cfg.A), generator=gen, device=dev) * 0.5
+    path = RegionProposalPath(cfg, B, C, dev, train=train)
+    args = (gt, label) if train else ()
+    graph = path.capture(fmap, score, coord, *args, seed=5)
+    keys = KEYS if train else KEYS[:5]
+    for _ in range(2):
+        fmap.copy_(torch.rand(fmap.shape, generator=gen, device=dev))
+        score.copy_(torch.rand(score.shape, generator=gen, device=dev))
+        coord.copy_(torch.randn(coord.shape, generator=gen, device=dev) * 0.5)
+        graph.replay()
+        torch.cuda.synchronize()
+        got = {k: getattr(path, k).clone() for k in keys} | {"pooled": path.pooled.clone()}
+        path.run(fmap, score, coord, *args, seed=5)
+        torch.cuda.synchronize()
+        for k, v in got.items():
+            assert torch.equal(v, getattr(path, k)), k

@@ -54,6 +54,9 @@ def path_times(cfg, B, C, train, seed):
                                                          out=path.pooled))
     if train:
         out["iou_assign"] = timed(lambda: ops.iou_assign(path.anchor.reshape(-1, 4), gt))
+    graph = path.capture(fmap, score, coord, gt, label, seed=1) if train else \
+        path.capture(fmap, score, coord)
+    out["whole_path_graph_replay"] = timed(graph.replay)
     out["images_per_s"] = B / (out["whole_path"]["mean_ms"] * 1e-3)
     out["mean_kept_proposals"] = float(path.keep_count.float().mean().item())
     return out
