@@ -210,17 +210,26 @@ nms_scan_kernel(const float4* __restrict__ boxes, const unsigned long long* __re
     const int nblk = min(NMS_CW, (K + 63) / 64 - cb0);
     // Everything a column block needs from memory is independent of the scan's own results
     // (the kept-tile words, the raw in-chunk words, the diagonal word, the box), so block
-    // jbl+1's loads are issued before block jbl is resolved and the serial part sees no load
-    // latency.  A wave owns kept tiles wave, wave+SW, ... and in-chunk rows wave, wave+SW, ...
+    // jbl+2's loads are issued before block jbl is resolved and the serial part sees no load
+    // latency.  A wave owns kept tiles wave, wave+SW, ... and
+    // in-chunk rows wave, wave+SW, ...
     constexpr int SW = NMS_SCAN_WAVES;
-    struct Pre { unsigned long long hitk, diag, mdw[NMS_CW / SW]; float4 box; };
+    // the kept-tile words stay raw until the block is resolved (an OR here would wait for
+    // the loads inside the prefetch); a wave holds at most KMAX of them in registers, the
+    // rest (post_n > 64 * SW * KMAX) are folded in at once
+    constexpr int KMAX = 8;
+    struct Pre { unsigned long long hk[KMAX], more, diag, mdw[NMS_CW / SW]; float4 box; };
     auto prefetch = [&](int jbl) {
         Pre p;
         const int col = jbl * 64 + lane;
         p.diag = wave == 0 ? md[(size_t)jbl * NMS_COLS + col] : 0ull;
-        p.hitk = 0ull;
-#pragma unroll 4
-        for (int kt = wave; kt < nkt; kt += SW) p.hitk |= mk[(size_t)kt * NMS_COLS + col];
+#pragma unroll
+        for (int t = 0; t < KMAX; ++t) {
+            const int kt = wave + SW * t;
+            p.hk[t] = kt < nkt ? mk[(size_t)kt * NMS_COLS + col] : 0ull;
+        }
+        p.more = 0ull;
+        for (int kt = wave + SW * KMAX; kt < nkt; kt += SW) p.more |= mk[(size_t)kt * NMS_COLS + col];
 #pragma unroll
         for (int t = 0; t < NMS_CW / SW; ++t) {
             const int ibl = wave + SW * t;
@@ -231,14 +240,18 @@ nms_scan_kernel(const float4* __restrict__ boxes, const unsigned long long* __re
         return p;
     };
     Pre cur = prefetch(0);
+    Pre nxt = cur;
+    if (1 < nblk) nxt = prefetch(1);
 #pragma unroll 1
     for (int jbl = 0; jbl < nblk; ++jbl) {
         const int count = s_cnt;
         if (count >= post_n) break;                     // block-uniform
-        Pre nxt = cur;
-        if (jbl + 1 < nblk) nxt = prefetch(jbl + 1);    // block-uniform
+        Pre nn = nxt;
+        if (jbl + 2 < nblk) nn = prefetch(jbl + 2);     // block-uniform, two blocks ahead
         const int j0 = (cb0 + jbl) * 64;
-        unsigned long long hit = cur.hitk;
+        unsigned long long hit = cur.more;
+#pragma unroll
+        for (int t = 0; t < KMAX; ++t) hit |= cur.hk[t];
 #pragma unroll
         for (int t = 0; t < NMS_CW / SW; ++t) {
             const int ibl = wave + SW * t;
@@ -287,6 +300,7 @@ nms_scan_kernel(const float4* __restrict__ boxes, const unsigned long long* __re
         }
         __syncthreads();
         cur = nxt;
+        nxt = nn;
     }
     const int count = s_cnt;
     const bool finished = count >= post_n || last_chunk;
