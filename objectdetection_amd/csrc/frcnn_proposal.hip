@@ -68,6 +68,12 @@ constexpr int NMS_CW = 16;                      // column blocks per chunk
 #ifndef NMS_SCAN_WAVES
 #define NMS_SCAN_WAVES 4                        // waves of the scan workgroup (1, 2 or 4)
 #endif
+#ifndef NMS_SCAN_AHEAD
+#define NMS_SCAN_AHEAD 1                         // column blocks the scan's loads run ahead (1 or 2).
+                                                // 2 is a little faster alone but needs 140 VGPRs:
+                                                // beside a kernel whose waves hold 128 each such a
+                                                // wave waits for two of them to end on one SIMD
+#endif
 #ifndef NMS_MASK_WAVES
 #define NMS_MASK_WAVES 1                        // row tiles (waves) per mask workgroup: one-wave
                                                 // workgroups also get wave slots while another
@@ -210,8 +216,8 @@ nms_scan_kernel(const float4* __restrict__ boxes, const unsigned long long* __re
     const int nblk = min(NMS_CW, (K + 63) / 64 - cb0);
     // Everything a column block needs from memory is independent of the scan's own results
     // (the kept-tile words, the raw in-chunk words, the diagonal word, the box), so block
-    // jbl+2's loads are issued before block jbl is resolved and the serial part sees no load
-    // latency.  A wave owns kept tiles wave, wave+SW, ... and
+    // the loads of a later block are issued before block jbl is resolved and the serial part
+    // sees no load latency.  A wave owns kept tiles wave, wave+SW, ... and
     // in-chunk rows wave, wave+SW, ...
     constexpr int SW = NMS_SCAN_WAVES;
     // the kept-tile words stay raw until the block is resolved (an OR here would wait for
@@ -240,14 +246,21 @@ nms_scan_kernel(const float4* __restrict__ boxes, const unsigned long long* __re
         return p;
     };
     Pre cur = prefetch(0);
+#if NMS_SCAN_AHEAD == 2
     Pre nxt = cur;
     if (1 < nblk) nxt = prefetch(1);
+#endif
 #pragma unroll 1
     for (int jbl = 0; jbl < nblk; ++jbl) {
         const int count = s_cnt;
         if (count >= post_n) break;                     // block-uniform
+#if NMS_SCAN_AHEAD == 2
         Pre nn = nxt;
         if (jbl + 2 < nblk) nn = prefetch(jbl + 2);     // block-uniform, two blocks ahead
+#else
+        Pre nxt = cur;
+        if (jbl + 1 < nblk) nxt = prefetch(jbl + 1);    // block-uniform, one block ahead
+#endif
         const int j0 = (cb0 + jbl) * 64;
         unsigned long long hit = cur.more;
 #pragma unroll
@@ -300,7 +313,9 @@ nms_scan_kernel(const float4* __restrict__ boxes, const unsigned long long* __re
         }
         __syncthreads();
         cur = nxt;
+#if NMS_SCAN_AHEAD == 2
         nxt = nn;
+#endif
     }
     const int count = s_cnt;
     const bool finished = count >= post_n || last_chunk;
