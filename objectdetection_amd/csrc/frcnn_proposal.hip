@@ -137,7 +137,7 @@ __device__ __forceinline__ unsigned long long mask_tile(const NBox& a, float c1,
 
 // grid (ceil((KT + NMS_CW)/4), NMS_CW, B), 4 waves: wave = one row tile.
 // maskK [B][KT][NMS_COLS], maskD [B][NMS_CW][NMS_COLS].
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8)))
 nms_mask_kernel(const float4* __restrict__ boxes, int K, int cb0, int KT, int post_n, float thr,
                 float c1, float thr_lo, const int* __restrict__ done,
                 const int* __restrict__ count_g, const int32_t* __restrict__ keep_idx,
