@@ -55,6 +55,32 @@ flip_images_kernel(const float* __restrict__ src, const uint8_t* __restrict__ fl
     }
 }
 
+// the same with 16-byte stores (and 16-byte loads for images that are not flipped): one thread
+// per four consecutive elements of a row; needs W*C % 4 == 0 and 16-byte aligned tensors
+__global__ void __launch_bounds__(256)
+flip_images_vec4_kernel(const float* __restrict__ src, const uint8_t* __restrict__ flip,
+                        uint64_t seed, int image_base, int H, int W, int C,
+                        float* __restrict__ dst) {
+    const int b = blockIdx.z, y = blockIdx.y;
+    const bool f = flip_of(flip, b, seed, image_base);
+    const size_t row = ((size_t)b * H + y) * (size_t)W * C;
+    const int n4 = (W * C) >> 2;
+    const float4* s4 = reinterpret_cast<const float4*>(src + row);
+    float4* d4 = reinterpret_cast<float4*>(dst + row);
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += gridDim.x * blockDim.x) {
+        if (!f) { d4[q] = s4[q]; continue; }
+        const int i = q * 4;
+        int x = i / C, c = i - x * C;
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            v[u] = src[row + (size_t)(W - 1 - x) * C + c];
+            if (++c == C) { c = 0; ++x; }
+        }
+        d4[q] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
 }  // namespace frcnn
 
 using namespace frcnn;
@@ -81,8 +107,16 @@ extern "C" int frcnn_flip_images(const float* images, const uint8_t* flip, uint6
         return FRCNN_E_BADARG;
     if (B > 65535 || H > 65535 || (long long)W * C > 0x7FFFFFFFll) return FRCNN_E_UNSUPPORTED;
     const int n = W * C;
-    const int bx = n >= 1024 ? 4 : 1;
-    FRCNN_LAUNCH(flip_images_kernel, dim3(bx, H, B), dim3(256), 0, (hipStream_t)stream, images,
-                 flip, seed, image_base, H, W, C, out);
+    const bool vec4 = (n % 4) == 0 &&
+                      ((reinterpret_cast<uintptr_t>(images) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0;
+    if (vec4) {
+        const int bx = (n / 4 + 255) / 256 < 4 ? (n / 4 + 255) / 256 : 4;
+        FRCNN_LAUNCH(flip_images_vec4_kernel, dim3(bx, H, B), dim3(256), 0, (hipStream_t)stream,
+                     images, flip, seed, image_base, H, W, C, out);
+    } else {
+        const int bx = n >= 1024 ? 4 : 1;
+        FRCNN_LAUNCH(flip_images_kernel, dim3(bx, H, B), dim3(256), 0, (hipStream_t)stream, images,
+                     flip, seed, image_base, H, W, C, out);
+    }
     return FRCNN_OK;
 }

@@ -100,6 +100,42 @@ def main():
     res["config5_B8_roi_backward"] = timed(
         lambda: ops.roi_crop_pool_bwd(dY, path.winner, path.proposed, tuple(fmap.shape),
                                       cfg1.crop, cfg1.pool), reps=3, warm=1)
+    # the steps either side of the path, batch 64 of the 600x1000 workload
+    B = 64
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    R, NC, S = cfg1.post_n, cfg1.num_classes, cfg1.head_batch
+    prop = torch.rand((B, R, 2), generator=g, device=dev) * 0.6
+    prop = torch.cat([prop, prop + 0.05 + torch.rand((B, R, 2), generator=g, device=dev) * 0.3], -1).clamp(0, 1)
+    cls_prob = torch.softmax(torch.randn((B, R, NC), generator=g, device=dev) * 3, -1)
+    reg = torch.randn((B, R, NC * 4), generator=g, device=dev) * 0.3
+    res["next_detect_postprocess_B64"] = timed(lambda: ops.detect_postprocess(prop, cls_prob, reg))
+    H, W, A, Sr = cfg1.H, cfg1.W, cfg1.A, cfg1.rpn_batch
+    pobj = torch.rand((B, H, W, A), generator=g, device=dev)
+    preg = torch.randn((B, H, W, A, 4), generator=g, device=dev)
+    pos = torch.stack([torch.randint(0, H, (B, Sr), generator=g, device=dev),
+                       torch.randint(0, W, (B, Sr), generator=g, device=dev),
+                       torch.randint(0, A, (B, Sr), generator=g, device=dev)], -1)
+    lab = (torch.rand((B, Sr), generator=g, device=dev) < 0.5).float()
+    rgt = torch.randn((B, Sr, 4), generator=g, device=dev)
+    res["next_rpn_loss_with_grads_B64"] = timed(lambda: ops.rpn_loss(pobj, preg, pos, lab, rgt))
+    tindex = torch.randint(0, R, (B, S), generator=g, device=dev)
+    hl = torch.nn.functional.one_hot(torch.randint(0, NC, (B, S), generator=g, device=dev), NC).float()
+    gm = (torch.rand((B, S), generator=g, device=dev) < 0.3).int()
+    gc = torch.randn((B, S, 4), generator=g, device=dev)
+    res["next_head_loss_with_grads_B64"] = timed(
+        lambda: ops.head_loss(cls_prob, reg, tindex, hl, gm, gc))
+    counts = torch.randint(1, cfg1.G + 1, (B,), generator=g, device=dev)
+    offs = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), counts.cumsum(0)]).int()
+    total = int(offs[-1])
+    rb = torch.rand((total, 4), generator=g, device=dev)
+    rl = torch.randint(0, 20, (total,), generator=g, device=dev)
+    res["next_pad_gt_with_flip_B64"] = timed(
+        lambda: ops.pad_gt(rb, rl, offs, cfg1.G, use_flip=True, seed=3))
+    imgs = torch.rand((B, 600, 1000, 3), generator=g, device=dev)
+    t = timed(lambda: ops.flip_images(imgs, seed=3), reps=5)
+    t["GBps_read_plus_write"] = 2 * imgs.numel() * 4 / (t["mean_ms"] * 1e-3) / 1e9
+    res["next_flip_images_B64_600x1000x3"] = t
     txt = json.dumps(res, indent=1)
     print(txt)
     if len(sys.argv) > 1:
