@@ -1009,12 +1009,23 @@ __device__ __forceinline__ bool axis_reaches(float c1, float c2, int dim, int n,
     return (float)target >= lo && (float)target <= hi;      // NaN -> false
 }
 
-template <int POOL, int NQ>
+template <int POOL, int NQ, int LW>
 __global__ void __launch_bounds__(64)
 roi_bwd_wave_kernel(const float* __restrict__ dY, const uint8_t* __restrict__ winner,
                     const float4* __restrict__ rois, int R, int H, int W, int C, int ch, int cw,
                     float* __restrict__ dfmap) {
-    const int x = blockIdx.x, y = blockIdx.y, b = blockIdx.z;
+    // The sample geometry of a candidate takes LW lanes per axis (crop <= LW), so one
+    // evaluation serves NC = 32 / LW candidates: lanes [2*LW*t, 2*LW*t + LW) hold the sample
+    // rows of candidate t, the next LW lanes its sample columns.
+    constexpr int NC = 32 / LW;
+    constexpr uint32_t FIELD = LW == 32 ? 0xFFFFFFFFu : ((1u << (LW & 31)) - 1u);
+    // Workgroups go to the 8 XCDs round-robin, each XCD with its own L2.  Neighbouring cells
+    // read the same dY bins at about the same time (all walk the RoIs in ascending order), so
+    // an XCD takes a contiguous run of cells (a band of rows): gridDim.x is the cell count
+    // rounded up to a multiple of 8, workgroup L is cell (L % 8) * gridDim.x / 8 + L / 8.
+    const int cell = (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    if (cell >= H * W) return;
+    const int x = cell % W, y = cell / W, b = blockIdx.z;
     const int lane = threadIdx.x;
     const int ph = ch / POOL, pw = cw / POOL;
     const int C4 = C >> 2;
@@ -1022,8 +1033,10 @@ roi_bwd_wave_kernel(const float* __restrict__ dY, const uint8_t* __restrict__ wi
 #pragma unroll
     for (int u = 0; u < NQ; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     const float4* rb = rois + (size_t)b * R;
-    const bool isx = lane >= 32;
-    const int s = lane & 31;
+    const int field = lane / LW;
+    const int ci = field >> 1;                               // this lane's candidate of the group
+    const bool isx = field & 1;
+    const int s = lane & (LW - 1);
     const int target = isx ? x : y;
     const int ns = isx ? cw : ch, dim = isx ? W : H;
 #pragma unroll 1
@@ -1038,18 +1051,38 @@ roi_bwd_wave_kernel(const float* __restrict__ dY, const uint8_t* __restrict__ wi
         unsigned long long m = __ballot(cand);
 #pragma unroll 1
         while (m != 0ull) {                                   // wave-uniform
-            const int l = __ffsll((long long)m) - 1;
-            m &= m - 1ull;
-            const float by1 = rlf(box.x, l), bx1 = rlf(box.y, l);
-            const float by2 = rlf(box.z, l), bx2 = rlf(box.w, l);
+            // the next NC candidates (RoI ascending), their corners selected per lane
+            int lc[NC];
+            int nc = 0;
+            float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+            for (int t = 0; t < NC; ++t) {
+                lc[t] = 0;
+                if (m != 0ull) {                              // wave-uniform
+                    lc[t] = __ffsll((long long)m) - 1;
+                    m &= m - 1ull;
+                    nc = t + 1;
+                    const float by1 = rlf(box.x, lc[t]), bx1 = rlf(box.y, lc[t]);
+                    const float by2 = rlf(box.z, lc[t]), bx2 = rlf(box.w, lc[t]);
+                    if (ci == t) { c1 = isx ? bx1 : by1; c2 = isx ? bx2 : by2; }
+                }
+            }
             int lo = 0, hi = 0, ok = 0;
             float fr = 0.f;
-            if (s < ns) axis_sample(isx ? bx1 : by1, isx ? bx2 : by2, dim, ns, s, lo, hi, fr, ok);
-            const bool v = s < ns && ok;
+            const bool act = s < ns && ci < nc;
+            if (act) axis_sample(c1, c2, dim, ns, s, lo, hi, fr, ok);
+            const bool v = act && ok;
             const unsigned long long mlo = __ballot(v && lo == target);
             const unsigned long long mhi = __ballot(v && hi == target);
-            const uint32_t ylo_m = (uint32_t)mlo, yhi_m = (uint32_t)mhi;
-            const uint32_t xlo_m = (uint32_t)(mlo >> 32), xhi_m = (uint32_t)(mhi >> 32);
+#pragma unroll 1
+            for (int t = 0; t < nc; ++t) {
+            const int sh = t * 2 * LW;                        // first lane of candidate t
+            const int l = t == 0 ? lc[0] : lc[NC - 1];
+            static_assert(NC <= 2, "candidate t is picked from lc[0] / lc[1]");
+            const uint32_t ylo_m = (uint32_t)(mlo >> sh) & FIELD;
+            const uint32_t yhi_m = (uint32_t)(mhi >> sh) & FIELD;
+            const uint32_t xlo_m = (uint32_t)(mlo >> (sh + LW)) & FIELD;
+            const uint32_t xhi_m = (uint32_t)(mhi >> (sh + LW)) & FIELD;
             uint32_t ym = ylo_m | yhi_m;
             const uint32_t xm_all = xlo_m | xhi_m;
             if (ym == 0u || xm_all == 0u) continue;
@@ -1057,55 +1090,63 @@ roi_bwd_wave_kernel(const float* __restrict__ dY, const uint8_t* __restrict__ wi
             while (ym != 0u) {
                 const int sy = __ffs((int)ym) - 1;
                 ym &= ym - 1u;
-                const float ly = rlf(fr, sy);
+                const float ly = rlf(fr, sh + sy);
                 const bool top = (ylo_m >> sy) & 1u, bot = (yhi_m >> sy) & 1u;
                 const float wt = 1.0f - ly, wb = ly;
                 uint32_t xm = xm_all;
                 while (xm != 0u) {
                     const int sx = __ffs((int)xm) - 1;
                     xm &= xm - 1u;
-                    const float lx = rlf(fr, 32 + sx);
+                    const float lx = rlf(fr, sh + LW + sx);
                     const bool left = (xlo_m >> sx) & 1u, right = (xhi_m >> sx) & 1u;
                     const float wl = 1.0f - lx, wr = lx;
                     const uint32_t k = (uint32_t)((sy % POOL) * POOL + (sx % POOL));
                     const size_t o = rbase + (size_t)((sy / POOL) * pw + (sx / POOL)) * C;
+                    // all loads of the pair go out before the first use
+                    float4 gq[NQ];
+                    uint32_t wq[NQ];
 #pragma unroll
                     for (int u = 0; u < NQ; ++u) {
                         const int c4 = lane + 64 * u;
-                        if (c4 >= C4) break;
-                        float4 g = *reinterpret_cast<const float4*>(dY + o + c4 * 4);
-                        if (POOL > 1) {
-                            const uint32_t wv = *reinterpret_cast<const uint32_t*>(winner + o + c4 * 4);
-                            if ((wv & 0xFFu) != k) g.x = 0.f;
-                            if (((wv >> 8) & 0xFFu) != k) g.y = 0.f;
-                            if (((wv >> 16) & 0xFFu) != k) g.z = 0.f;
-                            if ((wv >> 24) != k) g.w = 0.f;
-                        }
-                        // a non-winner channel adds +0 (x + 0 == x): same value as skipping it
-                        if (top) {
-                            const float4 d = make_float4(wt * g.x, wt * g.y, wt * g.z, wt * g.w);
-                            if (left) {
-                                acc[u].x += wl * d.x; acc[u].y += wl * d.y;
-                                acc[u].z += wl * d.z; acc[u].w += wl * d.w;
-                            }
-                            if (right) {
-                                acc[u].x += wr * d.x; acc[u].y += wr * d.y;
-                                acc[u].z += wr * d.z; acc[u].w += wr * d.w;
-                            }
-                        }
-                        if (bot) {
-                            const float4 d = make_float4(wb * g.x, wb * g.y, wb * g.z, wb * g.w);
-                            if (left) {
-                                acc[u].x += wl * d.x; acc[u].y += wl * d.y;
-                                acc[u].z += wl * d.z; acc[u].w += wl * d.w;
-                            }
-                            if (right) {
-                                acc[u].x += wr * d.x; acc[u].y += wr * d.y;
-                                acc[u].z += wr * d.z; acc[u].w += wr * d.w;
-                            }
+                        gq[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        wq[u] = 0u;
+                        if (c4 < C4) {
+                            gq[u] = *reinterpret_cast<const float4*>(dY + o + c4 * 4);
+                            if (POOL > 1)
+                                wq[u] = *reinterpret_cast<const uint32_t*>(winner + o + c4 * 4);
                         }
                     }
+                    if (POOL > 1) {
+                        // a non-winner channel adds +0 (x + 0 == x): same value as skipping it
+#pragma unroll
+                        for (int u = 0; u < NQ; ++u) {
+                            const uint32_t wv = wq[u];
+                            if ((wv & 0xFFu) != k) gq[u].x = 0.f;
+                            if (((wv >> 8) & 0xFFu) != k) gq[u].y = 0.f;
+                            if (((wv >> 16) & 0xFFu) != k) gq[u].z = 0.f;
+                            if ((wv >> 24) != k) gq[u].w = 0.f;
+                        }
+                    }
+                    // corners in the order TL, TR, BL, BR; most pairs have one.  The empty asm
+                    // keeps each corner a (wave-uniform) branch: as selects, every pair would
+                    // pay for all four
+#define FRCNN_CORNER(cond, wy, wx)                                                               \
+                    if (cond) {                                                                  \
+                        asm volatile("");                                                        \
+                        _Pragma("unroll") for (int u = 0; u < NQ; ++u) {                         \
+                            const float4 g = gq[u];                                              \
+                            const float4 d = make_float4(wy * g.x, wy * g.y, wy * g.z, wy * g.w); \
+                            acc[u].x += wx * d.x; acc[u].y += wx * d.y;                          \
+                            acc[u].z += wx * d.z; acc[u].w += wx * d.w;                          \
+                        }                                                                        \
+                    }
+                    FRCNN_CORNER(top && left, wt, wl)
+                    FRCNN_CORNER(top && right, wt, wr)
+                    FRCNN_CORNER(bot && left, wb, wl)
+                    FRCNN_CORNER(bot && right, wb, wr)
+#undef FRCNN_CORNER
                 }
+            }
             }
         }
     }
@@ -1196,9 +1237,17 @@ extern "C" int frcnn_roi_crop_pool_bwd(const float* dY, const uint8_t* winner, c
     hipStream_t st = (hipStream_t)stream;
     if (crop_h <= 32 && crop_w <= 32) {
         const int nq = (C / 4 + 63) / 64;                 // channel quads per lane, <= 8
+        const bool pack2 = crop_h <= 16 && crop_w <= 16;      // two candidates per evaluation
+        const dim3 cgrid((unsigned)(((long long)H * W + 7) / 8 * 8), 1, (unsigned)B);
 #define FRCNN_BWD(P, Q)                                                                          \
-    FRCNN_LAUNCH((roi_bwd_wave_kernel<P, Q>), grid, dim3(64), 0, st, dY, winner, rb, R, H, W, C,  \
-                 crop_h, crop_w, dfmap)
+    do {                                                                                         \
+        if (pack2)                                                                               \
+            FRCNN_LAUNCH((roi_bwd_wave_kernel<P, Q, 16>), cgrid, dim3(64), 0, st, dY, winner, rb, \
+                         R, H, W, C, crop_h, crop_w, dfmap);                                     \
+        else                                                                                     \
+            FRCNN_LAUNCH((roi_bwd_wave_kernel<P, Q, 32>), cgrid, dim3(64), 0, st, dY, winner, rb, \
+                         R, H, W, C, crop_h, crop_w, dfmap);                                     \
+    } while (0)
 #define FRCNN_BWD_P(P)                                                                           \
     do {                                                                                         \
         if (nq <= 1) FRCNN_BWD(P, 1); else if (nq <= 2) FRCNN_BWD(P, 2);                          \
