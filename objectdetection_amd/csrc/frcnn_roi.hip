@@ -1009,6 +1009,81 @@ __device__ __forceinline__ bool axis_reaches(float c1, float c2, int dim, int n,
     return (float)target >= lo && (float)target <= hi;      // NaN -> false
 }
 
+// One candidate RoI applied to one cell.  ylo_m / yhi_m: sample rows whose floor / ceil row is
+// the cell's row, xlo_m / xhi_m likewise for columns; `fr` holds the lerp fraction of sample
+// row sy in lane ylane0 + sy and of sample column sx in lane xlane0 + sx.  Order: sample
+// (sy,sx) row-major, corner TL,TR,BL,BR.
+template <int POOL, int NQ>
+__device__ __forceinline__ void bwd_apply_candidate(
+    float4 (&acc)[NQ], const float* __restrict__ dY, const uint8_t* __restrict__ winner,
+    size_t rbase, int pw, int C, int C4, int lane, uint32_t ylo_m, uint32_t yhi_m, uint32_t xlo_m,
+    uint32_t xhi_m, float fr, int ylane0, int xlane0) {
+    uint32_t ym = ylo_m | yhi_m;
+    const uint32_t xm_all = xlo_m | xhi_m;
+    if (ym == 0u || xm_all == 0u) return;
+    while (ym != 0u) {
+        const int sy = __ffs((int)ym) - 1;
+        ym &= ym - 1u;
+        const float ly = rlf(fr, ylane0 + sy);
+        const bool top = (ylo_m >> sy) & 1u, bot = (yhi_m >> sy) & 1u;
+        const float wt = 1.0f - ly, wb = ly;
+        uint32_t xm = xm_all;
+        while (xm != 0u) {
+            const int sx = __ffs((int)xm) - 1;
+            xm &= xm - 1u;
+            const float lx = rlf(fr, xlane0 + sx);
+            const bool left = (xlo_m >> sx) & 1u, right = (xhi_m >> sx) & 1u;
+            const float wl = 1.0f - lx, wr = lx;
+            const uint32_t k = (uint32_t)((sy % POOL) * POOL + (sx % POOL));
+            const size_t o = rbase + (size_t)((sy / POOL) * pw + (sx / POOL)) * C;
+            // all loads of the pair go out before the first use
+            float4 gq[NQ];
+            uint32_t wq[NQ];
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) {
+                const int c4 = lane + 64 * u;
+                gq[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                wq[u] = 0u;
+                if (c4 < C4) {
+                    gq[u] = *reinterpret_cast<const float4*>(dY + o + c4 * 4);
+                    if (POOL > 1)
+                        wq[u] = *reinterpret_cast<const uint32_t*>(winner + o + c4 * 4);
+                }
+            }
+            if (POOL > 1) {
+                // a non-winner channel adds +0 (x + 0 == x): same value as skipping it
+#pragma unroll
+                for (int u = 0; u < NQ; ++u) {
+                    const uint32_t wv = wq[u];
+                    if ((wv & 0xFFu) != k) gq[u].x = 0.f;
+                    if (((wv >> 8) & 0xFFu) != k) gq[u].y = 0.f;
+                    if (((wv >> 16) & 0xFFu) != k) gq[u].z = 0.f;
+                    if ((wv >> 24) != k) gq[u].w = 0.f;
+                }
+            }
+            // corners in the order TL, TR, BL, BR; most pairs have one.  The empty asm
+            // keeps each corner a (wave-uniform) branch: as selects, every pair would
+            // pay for all four
+#define FRCNN_CORNER(cond, wy, wx)                                                               \
+            if (cond) {                                                                  \
+                asm volatile("");                                                        \
+                _Pragma("unroll") for (int u = 0; u < NQ; ++u) {                         \
+                    const float4 g = gq[u];                                              \
+                    const float4 d = make_float4(wy * g.x, wy * g.y, wy * g.z, wy * g.w); \
+                    acc[u].x += wx * d.x; acc[u].y += wx * d.y;                          \
+                    acc[u].z += wx * d.z; acc[u].w += wx * d.w;                          \
+                }                                                                        \
+            }
+            FRCNN_CORNER(top && left, wt, wl)
+            FRCNN_CORNER(top && right, wt, wr)
+            FRCNN_CORNER(bot && left, wb, wl)
+            FRCNN_CORNER(bot && right, wb, wr)
+#undef FRCNN_CORNER
+        }
+    }
+
+}
+
 template <int POOL, int NQ, int LW>
 __global__ void __launch_bounds__(64)
 roi_bwd_wave_kernel(const float* __restrict__ dY, const uint8_t* __restrict__ winner,
@@ -1083,70 +1158,9 @@ roi_bwd_wave_kernel(const float* __restrict__ dY, const uint8_t* __restrict__ wi
             const uint32_t yhi_m = (uint32_t)(mhi >> sh) & FIELD;
             const uint32_t xlo_m = (uint32_t)(mlo >> (sh + LW)) & FIELD;
             const uint32_t xhi_m = (uint32_t)(mhi >> (sh + LW)) & FIELD;
-            uint32_t ym = ylo_m | yhi_m;
-            const uint32_t xm_all = xlo_m | xhi_m;
-            if (ym == 0u || xm_all == 0u) continue;
             const size_t rbase = ((size_t)b * R + (r0 + l)) * (size_t)(ph * pw) * C;
-            while (ym != 0u) {
-                const int sy = __ffs((int)ym) - 1;
-                ym &= ym - 1u;
-                const float ly = rlf(fr, sh + sy);
-                const bool top = (ylo_m >> sy) & 1u, bot = (yhi_m >> sy) & 1u;
-                const float wt = 1.0f - ly, wb = ly;
-                uint32_t xm = xm_all;
-                while (xm != 0u) {
-                    const int sx = __ffs((int)xm) - 1;
-                    xm &= xm - 1u;
-                    const float lx = rlf(fr, sh + LW + sx);
-                    const bool left = (xlo_m >> sx) & 1u, right = (xhi_m >> sx) & 1u;
-                    const float wl = 1.0f - lx, wr = lx;
-                    const uint32_t k = (uint32_t)((sy % POOL) * POOL + (sx % POOL));
-                    const size_t o = rbase + (size_t)((sy / POOL) * pw + (sx / POOL)) * C;
-                    // all loads of the pair go out before the first use
-                    float4 gq[NQ];
-                    uint32_t wq[NQ];
-#pragma unroll
-                    for (int u = 0; u < NQ; ++u) {
-                        const int c4 = lane + 64 * u;
-                        gq[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        wq[u] = 0u;
-                        if (c4 < C4) {
-                            gq[u] = *reinterpret_cast<const float4*>(dY + o + c4 * 4);
-                            if (POOL > 1)
-                                wq[u] = *reinterpret_cast<const uint32_t*>(winner + o + c4 * 4);
-                        }
-                    }
-                    if (POOL > 1) {
-                        // a non-winner channel adds +0 (x + 0 == x): same value as skipping it
-#pragma unroll
-                        for (int u = 0; u < NQ; ++u) {
-                            const uint32_t wv = wq[u];
-                            if ((wv & 0xFFu) != k) gq[u].x = 0.f;
-                            if (((wv >> 8) & 0xFFu) != k) gq[u].y = 0.f;
-                            if (((wv >> 16) & 0xFFu) != k) gq[u].z = 0.f;
-                            if ((wv >> 24) != k) gq[u].w = 0.f;
-                        }
-                    }
-                    // corners in the order TL, TR, BL, BR; most pairs have one.  The empty asm
-                    // keeps each corner a (wave-uniform) branch: as selects, every pair would
-                    // pay for all four
-#define FRCNN_CORNER(cond, wy, wx)                                                               \
-                    if (cond) {                                                                  \
-                        asm volatile("");                                                        \
-                        _Pragma("unroll") for (int u = 0; u < NQ; ++u) {                         \
-                            const float4 g = gq[u];                                              \
-                            const float4 d = make_float4(wy * g.x, wy * g.y, wy * g.z, wy * g.w); \
-                            acc[u].x += wx * d.x; acc[u].y += wx * d.y;                          \
-                            acc[u].z += wx * d.z; acc[u].w += wx * d.w;                          \
-                        }                                                                        \
-                    }
-                    FRCNN_CORNER(top && left, wt, wl)
-                    FRCNN_CORNER(top && right, wt, wr)
-                    FRCNN_CORNER(bot && left, wb, wl)
-                    FRCNN_CORNER(bot && right, wb, wr)
-#undef FRCNN_CORNER
-                }
-            }
+            bwd_apply_candidate<POOL, NQ>(acc, dY, winner, rbase, pw, C, C4, lane, ylo_m, yhi_m,
+                                          xlo_m, xhi_m, fr, sh, sh + LW);
             }
         }
     }
