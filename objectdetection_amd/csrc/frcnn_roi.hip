@@ -1012,11 +1012,11 @@ __device__ __forceinline__ bool axis_reaches(float c1, float c2, int dim, int n,
 // One candidate RoI applied to one cell.  ylo_m / yhi_m: sample rows whose floor / ceil row is
 // the cell's row, xlo_m / xhi_m likewise for columns; `fr` holds the lerp fraction of sample
 // row sy in lane ylane0 + sy and of sample column sx in lane xlane0 + sx.  Order: sample
-// (sy,sx) row-major, corner TL,TR,BL,BR.
+// (sy,sx) row-major, corner TL,TR,BL,BR.  cq = the lane's first channel quad.
 template <int POOL, int NQ>
 __device__ __forceinline__ void bwd_apply_candidate(
     float4 (&acc)[NQ], const float* __restrict__ dY, const uint8_t* __restrict__ winner,
-    size_t rbase, int pw, int C, int C4, int lane, uint32_t ylo_m, uint32_t yhi_m, uint32_t xlo_m,
+    size_t rbase, int pw, int C, int C4, int cq, uint32_t ylo_m, uint32_t yhi_m, uint32_t xlo_m,
     uint32_t xhi_m, float fr, int ylane0, int xlane0) {
     uint32_t ym = ylo_m | yhi_m;
     const uint32_t xm_all = xlo_m | xhi_m;
@@ -1041,7 +1041,7 @@ __device__ __forceinline__ void bwd_apply_candidate(
             uint32_t wq[NQ];
 #pragma unroll
             for (int u = 0; u < NQ; ++u) {
-                const int c4 = lane + 64 * u;
+                const int c4 = cq + 64 * u;
                 gq[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 wq[u] = 0u;
                 if (c4 < C4) {
@@ -1102,6 +1102,7 @@ roi_bwd_wave_kernel(const float* __restrict__ dY, const uint8_t* __restrict__ wi
     if (cell >= H * W) return;
     const int x = cell % W, y = cell / W, b = blockIdx.z;
     const int lane = threadIdx.x;
+    const int cq = (int)blockIdx.y * 64 * NQ + lane;         // blockIdx.y = slice of 256*NQ channels
     const int ph = ch / POOL, pw = cw / POOL;
     const int C4 = C >> 2;
     float4 acc[NQ];
@@ -1159,7 +1160,7 @@ roi_bwd_wave_kernel(const float* __restrict__ dY, const uint8_t* __restrict__ wi
             const uint32_t xlo_m = (uint32_t)(mlo >> (sh + LW)) & FIELD;
             const uint32_t xhi_m = (uint32_t)(mhi >> (sh + LW)) & FIELD;
             const size_t rbase = ((size_t)b * R + (r0 + l)) * (size_t)(ph * pw) * C;
-            bwd_apply_candidate<POOL, NQ>(acc, dY, winner, rbase, pw, C, C4, lane, ylo_m, yhi_m,
+            bwd_apply_candidate<POOL, NQ>(acc, dY, winner, rbase, pw, C, C4, cq, ylo_m, yhi_m,
                                           xlo_m, xhi_m, fr, sh, sh + LW);
             }
         }
@@ -1167,7 +1168,7 @@ roi_bwd_wave_kernel(const float* __restrict__ dY, const uint8_t* __restrict__ wi
     float* dst = dfmap + (((size_t)b * H + y) * W + x) * C;
 #pragma unroll
     for (int u = 0; u < NQ; ++u) {
-        const int c4 = lane + 64 * u;
+        const int c4 = cq + 64 * u;
         if (c4 < C4) *reinterpret_cast<float4*>(dst + c4 * 4) = acc[u];
     }
 }
@@ -1242,7 +1243,7 @@ extern "C" int frcnn_roi_crop_pool_bwd(const float* dY, const uint8_t* winner, c
     if (pool == 2 && !winner) return FRCNN_E_BADARG;
     if (crop_h % pool || crop_w % pool) return FRCNN_E_BADARG;
     if (crop_h > ROI_MAX_CROP || crop_w > ROI_MAX_CROP) return FRCNN_E_UNSUPPORTED;
-    if ((C % 4) != 0 || C > 4 * 4 * 128 || H > 65535 || B > 65535) return FRCNN_E_UNSUPPORTED;
+    if ((C % 4) != 0 || B > 65535 || (long long)H * W > 0x7FFFFFF0ll) return FRCNN_E_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(dY) % 16) || (reinterpret_cast<uintptr_t>(dfmap) % 16) ||
         (winner && (reinterpret_cast<uintptr_t>(winner) % 4)))
         return FRCNN_E_BADARG;
@@ -1250,9 +1251,12 @@ extern "C" int frcnn_roi_crop_pool_bwd(const float* dY, const uint8_t* winner, c
     const float4* rb = reinterpret_cast<const float4*>(rois);
     hipStream_t st = (hipStream_t)stream;
     if (crop_h <= 32 && crop_w <= 32) {
-        const int nq = (C / 4 + 63) / 64;                 // channel quads per lane, <= 8
+        const int nq = (C / 4 + 63) / 64;                 // channel quads per lane; above 8 the
+                                                          // channels are split over blockIdx.y
+        const int nqk = nq <= 1 ? 1 : nq <= 2 ? 2 : nq <= 4 ? 4 : 8;
+        const int nsl = (C / 4 + 64 * nqk - 1) / (64 * nqk);
         const bool pack2 = crop_h <= 16 && crop_w <= 16;      // two candidates per evaluation
-        const dim3 cgrid((unsigned)(((long long)H * W + 7) / 8 * 8), 1, (unsigned)B);
+        const dim3 cgrid((unsigned)(((long long)H * W + 7) / 8 * 8), (unsigned)nsl, (unsigned)B);
 #define FRCNN_BWD(P, Q)                                                                          \
     do {                                                                                         \
         if (pack2)                                                                               \
@@ -1272,6 +1276,7 @@ extern "C" int frcnn_roi_crop_pool_bwd(const float* dY, const uint8_t* winner, c
 #undef FRCNN_BWD
         return FRCNN_OK;
     }
+    if (C > 4 * 4 * 128 || H > 65535) return FRCNN_E_UNSUPPORTED;   // large-crop kernel's limits
     if (pool == 2)
         FRCNN_LAUNCH(roi_bwd_cl_kernel<2>, grid, block, 0, st, dY, winner, rb, R, H, W, C,
                            crop_h, crop_w, dfmap);

@@ -197,7 +197,7 @@ def test_roi_backward_exact(dev):
 
 
 @pytest.mark.parametrize("C,pool,crop,R", [(512, 2, (14, 14), 30), (320, 2, (14, 14), 20),
-                                              (64, 1, (6, 6), 25), (2048, 2, (8, 12), 6),
+                                              (64, 1, (6, 6), 25), (2048, 2, (8, 12), 6), (2304, 2, (4, 4), 3),
                                               (12, 2, (14, 14), 10)])
 def test_roi_backward_exact_shapes(dev, C, pool, crop, R):
     """wave-per-cell kernel with 1/2/8 channel quads per lane, ragged C, plain crop."""
