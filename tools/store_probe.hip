@@ -16,6 +16,8 @@ constexpr int C = 512, PH = 7, PW = 7;
 // mode 1: same, slice = blockIdx.x / R (a slice's blocks are dispatched together)
 // mode 2: wave = (roi, pooled row): 7 bins x 2 KB contiguous = 14 store instructions of 1 KB
 // mode 3: wave = (roi, 64-channel slice) but 256 threads: 4 waves, wave w takes rows w, w+4
+// mode 4: workgroup = (image, 16-channel slice), 16 waves, 147 KB of LDS (one per CU); wave w
+//         writes RoIs w, w+16, ...: 49 bins x 64 B, 16 bins per store instruction
 template <int MODE>
 __global__ void __launch_bounds__(256) probe(float* __restrict__ out, int R, int delay) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -40,6 +42,44 @@ __global__ void __launch_bounds__(256) probe(float* __restrict__ out, int R, int
 #pragma unroll
         for (int i = 0; i < 14; ++i) *reinterpret_cast<f32x4*>(base + i * 256) = v;
     }
+}
+
+__global__ void __launch_bounds__(1024) probe_slice16(float* __restrict__ out, int R) {
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int slice = blockIdx.x, b = blockIdx.y;
+    if (threadIdx.x == 0) lds[0] = 1.f;
+    f32x4 v = {1.f, 2.f, 3.f, (float)lane};
+    for (int r = wave; r < R; r += 16) {
+        float* base = out + ((size_t)b * R + r) * (PH * PW) * C + slice * 16 + (lane & 3) * 4;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int bin = t * 16 + (lane >> 2);
+            if (bin < PH * PW) *reinterpret_cast<f32x4*>(base + (size_t)bin * C) = v;
+        }
+    }
+}
+
+void run_slice16(float* out, int B, int R) {
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    const int lds = 147 * 1024;
+    CHECK(hipFuncSetAttribute((const void*)probe_slice16, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    dim3 grid(32, B), block(1024);
+    probe_slice16<<<grid, block, lds>>>(out, R);
+    CHECK(hipDeviceSynchronize());
+    float best = 1e9f;
+    for (int rep = 0; rep < 3; ++rep) {
+        CHECK(hipEventRecord(a));
+        probe_slice16<<<grid, block, lds>>>(out, R);
+        CHECK(hipEventRecord(b));
+        CHECK(hipEventSynchronize(b));
+        float ms = 0.f;
+        CHECK(hipEventElapsedTime(&ms, a, b));
+        if (ms < best) best = ms;
+    }
+    const double bytes = (double)B * R * PH * PW * C * 4;
+    printf("%-64s %7.3f ms  %6.2f TB/s\n", "workgroup = image x 16ch slice, 64 B pieces", best, bytes / best / 1e9);
 }
 
 template <int MODE>
@@ -72,5 +112,6 @@ int main() {
     run<1>("wave = roi x 64ch, slice-major blocks", out, B, R, 0);
     run<3>("4 waves per (roi, slice), rows interleaved", out, B, R, 0);
     run<2>("wave = roi x pooled row, 14 KB contiguous", out, B, R, 0);
+    run_slice16(out, B, R);
     return 0;
 }
