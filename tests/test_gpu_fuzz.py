@@ -4,7 +4,7 @@ example budget; a failing case is shrunk and printed with its arguments."""
 import numpy as np
 import pytest
 import torch
-from hypothesis import HealthCheck, given, settings, strategies as st
+from hypothesis import HealthCheck, example, given, settings, strategies as st
 
 from oracle import frcnn_oracle as O
 
@@ -86,6 +86,9 @@ def test_fuzz_anchor_assignment(seed, H, W, ns, nr, G, thr, mode):
 @given(seed=st.integers(0, 2**31 - 1), B=st.integers(1, 3), N=st.integers(1, 40000),
        kfrac=st.floats(0.0, 1.0), vals=st.sampled_from(["normal", "few", "zeros", "equal", "big"]),
        method=st.sampled_from(["lds", "sort"]))
+@example(seed=1, B=2, N=39999, kfrac=0.5, vals="few", method="sort")
+@example(seed=2, B=3, N=20000, kfrac=1.0, vals="zeros", method="lds")
+@example(seed=3, B=1, N=40000, kfrac=1.0, vals="equal", method="sort")
 def test_fuzz_topk(seed, B, N, kfrac, vals, method):
     from objectdetection_amd import ops
     rng = np.random.default_rng(seed)
@@ -111,6 +114,9 @@ def test_fuzz_topk(seed, B, N, kfrac, vals, method):
 @FUZZ
 @given(seed=st.integers(0, 2**31 - 1), B=st.integers(1, 2), K=st.integers(1, 3000),
        post_n=st.integers(1, 400), thr=st.sampled_from([0.3, 0.5, 0.7, 0.9]), mode=BOX_MODES)
+@example(seed=4, B=2, K=3000, post_n=400, thr=0.7, mode="clustered")
+@example(seed=5, B=1, K=2500, post_n=64, thr=0.3, mode="degenerate")
+@example(seed=6, B=2, K=1025, post_n=400, thr=0.9, mode="grid")
 def test_fuzz_nms(seed, B, K, post_n, thr, mode):
     from objectdetection_amd import ops
     rng = np.random.default_rng(seed)
@@ -130,6 +136,9 @@ CROPS = st.sampled_from([((14, 14), 2), ((14, 14), 1), ((7, 7), 1), ((6, 10), 2)
 @given(seed=st.integers(0, 2**31 - 1), B=st.integers(1, 2), H=st.integers(1, 20),
        W=st.integers(1, 20), C=st.sampled_from([4, 8, 12, 64, 68, 128, 192, 256, 6, 1]),
        R=st.integers(1, 10), cp=CROPS, mode=BOX_MODES, strided=st.booleans())
+@example(seed=7, B=2, H=20, W=20, C=192, R=10, cp=((14, 14), 2), mode="outside", strided=True)
+@example(seed=8, B=1, H=17, W=19, C=256, R=10, cp=((16, 16), 2), mode="grid", strided=False)
+@example(seed=9, B=2, H=20, W=3, C=68, R=9, cp=((6, 10), 2), mode="degenerate", strided=True)
 def test_fuzz_roi_forward_backward(seed, B, H, W, C, R, cp, mode, strided):
     from objectdetection_amd import ops
     crop, pool = cp
@@ -156,6 +165,8 @@ def test_fuzz_roi_forward_backward(seed, B, H, W, C, R, cp, mode, strided):
 @FUZZ
 @given(seed=st.integers(0, 2**31 - 1), B=st.integers(1, 3), R=st.integers(1, 600),
        G=st.integers(1, 60), batch=st.sampled_from([8, 64, 128]), mode=BOX_MODES)
+@example(seed=10, B=3, R=600, G=60, batch=128, mode="clustered")
+@example(seed=11, B=2, R=599, G=1, batch=64, mode="uniform")
 def test_fuzz_proposal_targets(seed, B, R, G, batch, mode):
     from objectdetection_amd import ops
     rng = np.random.default_rng(seed)
@@ -237,3 +248,108 @@ def test_fuzz_decode_encode(seed, B, n, clip, scale):
     fin = np.isfinite(renc)
     np.testing.assert_array_equal(np.isfinite(enc), fin)
     np.testing.assert_allclose(enc[fin], renc[fin], rtol=1e-5, atol=1e-5)
+
+
+@FUZZ
+@given(seed=st.integers(0, 2**31 - 1), B=st.integers(1, 3), R=st.integers(1, 700),
+       NC=st.sampled_from([2, 5, 21]), max_out=st.sampled_from([1, 10, 30, 100]),
+       sthr=st.sampled_from([0.0, 0.5, 0.9]), mode=BOX_MODES)
+@example(seed=12, B=3, R=700, NC=21, max_out=30, sthr=0.5, mode="clustered")
+def test_fuzz_detect_postprocess(seed, B, R, NC, max_out, sthr, mode):
+    """Class argmax, decode, background drop, final NMS and score cut: keep lists and classes
+    bit-exact on the device-decoded boxes, decoded boxes within 1e-5."""
+    from objectdetection_amd import ops
+    rng = np.random.default_rng(seed)
+    prop = np.stack([np.clip(draw_boxes(rng, R, mode), 0, 1) for _ in range(B)])
+    z = rng.normal(0, 3.0, (B, R, NC))
+    p = (np.exp(z) / np.exp(z).sum(-1, keepdims=True)).astype(np.float32)
+    if R > 4:
+        p[0, 1:4] = p[0, 1]                                  # equal scores -> lower index first
+    reg = rng.normal(0, 0.5, (B, R, NC * 4)).astype(np.float32)
+    bg = NC - 1
+    out = ops.detect_postprocess(T(prop), T(p), T(reg), bg_label=bg, max_out=max_out,
+                                 score_threshold=sthr)
+    ref = O.detect_postprocess(prop, p, reg, bg_label=bg, max_out=max_out, score_threshold=sthr)
+    np.testing.assert_array_equal(out["cls_arg"].cpu().numpy(), ref["argindex"])
+    dec = out["decoded"].cpu().numpy()
+    np.testing.assert_allclose(dec, ref["decoded"], rtol=1e-5, atol=1e-7)
+    score = np.take_along_axis(p, ref["argindex"].astype(np.int64)[..., None], 2)[..., 0]
+    for b in range(B):
+        fg = np.nonzero(ref["argindex"][b] != bg)[0]
+        n = 0
+        if fg.size:
+            sel, ssc = O.nms_with_scores(dec[b][fg], score[b][fg], max_out, 0.7)
+            ok = ssc >= np.float32(sthr)
+            n = int(ok.sum())
+            np.testing.assert_array_equal(out["src"][b].cpu().numpy()[:n], fg[sel[ok]])
+            np.testing.assert_array_equal(out["scores"][b].cpu().numpy()[:n], ssc[ok])
+        assert int(out["count"][b]) == n
+        assert (out["src"][b].cpu().numpy()[n:] == -1).all()
+
+
+@FUZZ
+@given(seed=st.integers(0, 2**31 - 1), B=st.integers(1, 4), H=st.integers(1, 9),
+       W=st.integers(1, 9), A=st.integers(1, 12), S=st.sampled_from([1, 16, 256]),
+       R=st.integers(1, 300), K=st.sampled_from([2, 7, 21]), pfrac=st.floats(0.0, 1.0))
+def test_fuzz_losses(seed, B, H, W, A, S, R, K, pfrac):
+    """RPN and head losses with their gradients, 1e-5 relative (f32 tree sums vs float64)."""
+    from objectdetection_amd import ops
+    rng = np.random.default_rng(seed)
+    pred_obj = rng.random((B, H, W, A), dtype=np.float32)
+    pred_reg = (rng.normal(size=(B, H, W, A, 4)) * 2).astype(np.float32)
+    S = min(S, H * W * A, R)                                  # samples are distinct anchors / proposals
+    flat = np.stack([rng.permutation(H * W * A)[:S] for _ in range(B)])
+    pos = np.stack(np.unravel_index(flat, (H, W, A)), -1).astype(np.int64)
+    label = (rng.random((B, S)) < pfrac).astype(np.float32)
+    reg_gt = (rng.normal(size=(B, S, 4)) * 2).astype(np.float32)
+    (cls, reg, tot), d_obj, d_reg = O.rpn_loss(pred_obj, pred_reg, pos, label, reg_gt)
+    out = ops.rpn_loss(T(pred_obj), T(pred_reg), T(pos), T(label), T(reg_gt))
+    np.testing.assert_allclose(out["loss"].cpu().numpy(), [cls, reg, tot], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(out["d_obj"].cpu().numpy(), d_obj, rtol=2e-5, atol=1e-9)
+    np.testing.assert_allclose(out["d_reg"].cpu().numpy(), d_reg, rtol=2e-5, atol=1e-9)
+    cls_prob = rng.random((B, R, K), dtype=np.float32) + np.float32(1e-3)
+    cls_prob /= cls_prob.sum(-1, keepdims=True)
+    hreg = (rng.normal(size=(B, R, K, 4)) * 2).astype(np.float32)
+    tindex = np.stack([rng.permutation(R)[:S] for _ in range(B)]).astype(np.int64)
+    c = rng.integers(0, K, (B, S))
+    onehot = np.eye(K, dtype=np.float32)[c]
+    gt_mask = (rng.random((B, S)) < pfrac).astype(np.int32)
+    gt_coord = (rng.normal(size=(B, S, 4)) * 3).astype(np.float32)
+    (hc, hr, ht), d_cls, d_hreg = O.head_loss(cls_prob, hreg, tindex, onehot, gt_mask, gt_coord)
+    ho = ops.head_loss(T(cls_prob), T(hreg), T(tindex), T(onehot), T(gt_mask), T(gt_coord))
+    np.testing.assert_allclose(ho["loss"].cpu().numpy(), [hc, hr, ht], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(ho["d_cls"].cpu().numpy(), d_cls, rtol=2e-5, atol=1e-9)
+    np.testing.assert_allclose(ho["d_reg"].cpu().numpy(), d_hreg, rtol=2e-5, atol=1e-9)
+
+
+@FUZZ
+@given(seed=st.integers(0, 2**31 - 1), B=st.integers(1, 6), G=st.integers(1, 50),
+       H=st.integers(1, 9), W=st.integers(1, 40), C=st.sampled_from([1, 3, 4]))
+def test_fuzz_input_side(seed, B, G, H, W, C):
+    """Ragged ground truth -> padded tensors with the flip of the boxes, and the image flip,
+    bit-exact, with explicit flags and with the counter-based decision."""
+    from objectdetection_amd import ops
+    rng = np.random.default_rng(seed)
+    counts = rng.integers(0, G + 1, B)
+    boxes = [draw_boxes(rng, int(n), "uniform") if n else np.zeros((0, 4), np.float32)
+             for n in counts]
+    labels = [rng.integers(0, 20, int(n)).astype(np.int64) for n in counts]
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    cat = np.concatenate(boxes) if off[-1] else np.zeros((0, 4), np.float32)
+    lab = np.concatenate(labels) if off[-1] else np.zeros((0,), np.int64)
+    img = rng.random((B, H, W, C), dtype=np.float32)
+    for flags in (rng.integers(0, 2, B).astype(np.uint8), None):
+        fl = None if flags is None else T(flags)
+        gt, gl, cnt = ops.pad_gt(T(cat), T(lab), T(off), G, flip=fl, use_flip=True, seed=seed,
+                                 image_base=2)
+        fimg = ops.flip_images(T(img), fl, seed=seed, image_base=2).cpu().numpy()
+        np.testing.assert_array_equal(cnt.cpu().numpy(), counts)
+        for b in range(B):
+            f = bool(flags[b]) if flags is not None else O.flip_decision(seed, 2 + b)
+            bb = boxes[b]
+            if f and bb.shape[0]:
+                _, _, bb = O.augmentation_data(img[b], labels[b], bb)
+            rb, rl = O.pad_gt(bb, labels[b], G)
+            np.testing.assert_array_equal(gt[b].cpu().numpy(), rb)
+            np.testing.assert_array_equal(gl[b].cpu().numpy(), rl)
+            np.testing.assert_array_equal(fimg[b], img[b][:, ::-1] if f else img[b])
