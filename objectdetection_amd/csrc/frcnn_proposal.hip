@@ -135,7 +135,9 @@ __device__ __forceinline__ unsigned long long mask_tile(const NBox& a, float c1,
     return mine;
 }
 
-// grid (ceil((KT + NMS_CW)/4), NMS_CW, B), 4 waves: wave = one row tile.
+// grid (ceil((KT + NMS_CW) / NMS_MASK_WAVES), NMS_CW, B), NMS_MASK_WAVES waves: wave = one row
+// tile.  Capped at 64 VGPRs: two such waves fit the registers one 128-VGPR wave of a kernel
+// running beside it frees.
 // maskK [B][KT][NMS_COLS], maskD [B][NMS_CW][NMS_COLS].
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8)))
 nms_mask_kernel(const float4* __restrict__ boxes, int K, int cb0, int KT, int post_n, float thr,
