@@ -32,7 +32,8 @@ def check(dev, boxes, thr, post_n):
 
 @pytest.mark.parametrize("K,post_n,spread", [(1, 4, 0.5), (63, 10, 0.5), (64, 64, 0.3),
                                              (65, 100, 0.3), (1000, 300, 0.2), (3000, 3000, 0.6),
-                                             (2500, 50, 0.1)])
+                                             (2500, 50, 0.1),
+                                             (6000, 5000, 0.03)])   # > 2048 kept: words beyond the registers
 def test_nms_sizes(dev, K, post_n, spread):
     rng = np.random.default_rng(K)
     check(dev, random_boxes(rng, 3, K, spread), 0.7, post_n)
