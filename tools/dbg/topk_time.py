@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Times both top-k entry points (with the fused decode) on the bench workload's scores."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from objectdetection_amd import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+cfg = bench.workload_cfg()
+anchor = ops.anchors(cfg.H, cfg.W, cfg.scales, cfg.ratios, cfg.base_w, cfg.base_h, dev).reshape(-1, 4)
+for B in (1, 4, 16, 64):
+    fmap, score, coord, gt, label = bench.make_inputs(cfg, B, 8, dev, 1000)
+    s, d = score.reshape(B, -1), coord.reshape(B, -1, 4)
+    ws = torch.empty(ops.topk_sort_workspace_bytes(B, s.shape[1]), dtype=torch.uint8, device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for method in ("lds", "sort"):
+        ts = []
+        for _ in range(8):
+            e0.record()
+            ops.topk(s, cfg.pre_k, anchor, d, method=method, workspace=ws if method == "sort" else None)
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        print(f"B={B} {method}: min {min(ts)*1e3:.1f} us  mean {np.mean(ts[2:])*1e3:.1f} us")
