@@ -143,7 +143,9 @@ int frcnn_topk_sort(const float* scores, int B, int N, int K,
  * keep_pos [B,post_n] i32 = kept positions in 0..K-1, -1 padded (may be NULL);
  * keep_count [B] i32 (may be NULL).
  * workspace: frcnn_nms_workspace_bytes(B,K,post_n) bytes, 256-byte aligned
- * (about 8 KB x (post_n/64 + 16) + 4 x post_n bytes per image; independent of K). */
+ * (about 8 KB x (post_n/64 + 16) + 4 x post_n bytes per image; independent of K); its
+ * contents on entry do not matter (nothing has to be cleared between calls).  Only kernel
+ * launches are issued, so the call can be recorded into a HIP graph. */
 size_t frcnn_nms_workspace_bytes(int B, int K, int post_n);
 int frcnn_nms(const float* boxes, int B, int K, float iou_threshold, int post_n,
               float* proposed, int32_t* keep_pos, int32_t* keep_count,
@@ -166,8 +168,9 @@ int frcnn_roi_crop_pool_fwd(const float* fmap, int B, int H, int W, int C,
  * The reference never differentiates the crop (stop_gradient,
  * Faster_RCNN/module/model.py:71); this is the exact adjoint, atomic-free: each
  * feature cell is owned by one thread group which gathers its contributions in
- * the fixed order RoI, bin, corner.  dY/winner as written by the forward;
- * dfmap [B,H,W,C] contiguous channels-last, fully overwritten. */
+ * the fixed order RoI ascending, sample (sy,sx) row-major, corner TL,TR,BL,BR.
+ * dY/winner as written by the forward; dfmap [B,H,W,C] contiguous channels-last, fully
+ * overwritten.  C % 4 == 0; crops above 32 x 32 need C <= 2048. */
 int frcnn_roi_crop_pool_bwd(const float* dY, const uint8_t* winner, const float* rois,
                             int B, int R, int H, int W, int C,
                             int crop_h, int crop_w, int pool,
