@@ -249,7 +249,7 @@ def main():
                 "algorithmic_bytes_per_launch": alg,
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:       # the CPU leg is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(cfg, fmap, score, coord, gt, label)
         print(json.dumps(out), flush=True)
     if dist is not None:
