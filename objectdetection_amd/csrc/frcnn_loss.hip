@@ -120,24 +120,46 @@ rpn_loss_finish_kernel(const float* __restrict__ pred_obj, const float* __restri
     if (!d_obj && !d_reg) return;
     const float w_cls = 2.0f / n_cls;
     const float w_reg = n_reg > 0.0f ? 1.0f / n_reg : 0.0f;
-    for (int i = threadIdx.x; i < S; i += LOSS_BLOCK) {
+    // The mini-batch can list one anchor twice (a negative's position is its rank in the
+    // valid-anchor list, module/data.py:108-118, and that rank can equal a positive's anchor
+    // id), and the gradient of a gather accumulates.  The first sample of an anchor owns its
+    // gradient and adds the later ones in sample order: no atomics, one fixed order.
+    auto anchor_of = [&](int i) -> long long {
         const int64_t* p3 = pos + ((size_t)b * S + i) * 3;
         const int64_t y = p3[0], x = p3[1], a = p3[2];
-        if (y < 0 || y >= H || x < 0 || x >= W || a < 0 || a >= A) continue;
-        const size_t idx = (size_t)b * N + (size_t)((y * W + x) * A + a);
-        const float lab = label[(size_t)b * S + i];
-        float d;
-        (void)bce(lab, pred_obj[idx], d);
-        if (d_obj) d_obj[idx] = w_cls * d;
-        if (d_reg && (int64_t)lab == 1) {
-            const float4 t = reinterpret_cast<const float4*>(reg_gt)[(size_t)b * S + i];
-            const float4 p = reinterpret_cast<const float4*>(pred_reg)[idx];
-            float4 g;
-            (void)huber(t.x, p.x, g.x); (void)huber(t.y, p.y, g.y);
-            (void)huber(t.z, p.z, g.z); (void)huber(t.w, p.w, g.w);
-            g.x *= w_reg; g.y *= w_reg; g.z *= w_reg; g.w *= w_reg;
-            reinterpret_cast<float4*>(d_reg)[idx] = g;
+        if (y < 0 || y >= H || x < 0 || x >= W || a < 0 || a >= A) return -1;
+        return (long long)((y * W + x) * A + a);
+    };
+    for (int i = threadIdx.x; i < S; i += LOSS_BLOCK) {
+        const long long an = anchor_of(i);
+        if (an < 0) continue;
+        bool owner = true;
+        for (int j = 0; j < i; ++j)
+            if (anchor_of(j) == an) { owner = false; break; }
+        if (!owner) continue;
+        const size_t idx = (size_t)b * N + (size_t)an;
+        const float p_obj = pred_obj[idx];
+        const float4 p = reinterpret_cast<const float4*>(pred_reg)[idx];
+        float g_obj = 0.f;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        bool any_pos = false;
+        for (int j = i; j < S; ++j) {
+            if (j != i && anchor_of(j) != an) continue;
+            const float lab = label[(size_t)b * S + j];
+            float d;
+            (void)bce(lab, p_obj, d);
+            g_obj += w_cls * d;
+            if ((int64_t)lab == 1) {
+                const float4 t = reinterpret_cast<const float4*>(reg_gt)[(size_t)b * S + j];
+                float4 h;
+                (void)huber(t.x, p.x, h.x); (void)huber(t.y, p.y, h.y);
+                (void)huber(t.z, p.z, h.z); (void)huber(t.w, p.w, h.w);
+                g.x += h.x * w_reg; g.y += h.y * w_reg; g.z += h.z * w_reg; g.w += h.w * w_reg;
+                any_pos = true;
+            }
         }
+        if (d_obj) d_obj[idx] = g_obj;
+        if (d_reg && any_pos) reinterpret_cast<float4*>(d_reg)[idx] = g;
     }
 }
 
@@ -225,36 +247,52 @@ head_loss_finish_kernel(const float* __restrict__ cls_prob, const float* __restr
     if (!d_cls && !d_reg) return;
     const float w_cls = 2.0f / n_cls;
     const float w_reg = n_reg > 0.0f ? 1.0f / n_reg : 0.0f;
+    // tindex rows are distinct when they come from frcnn_sample_proposals; a caller's own list
+    // may repeat a proposal, and the gradient of a gather accumulates: the first sample of a
+    // proposal owns its rows and adds the later ones in sample order.
     for (int i = threadIdx.x; i < S; i += LOSS_BLOCK) {
         const int64_t r = tindex[(size_t)b * S + i];
         if (r < 0 || r >= R) continue;
-        const float* y = label + ((size_t)b * S + i) * K;
+        bool owner = true;
+        for (int j = 0; j < i; ++j)
+            if (tindex[(size_t)b * S + j] == r) { owner = false; break; }
+        if (!owner) continue;
         const size_t row = (size_t)b * R + (size_t)r;
         const float* p = cls_prob + row * K;
-        if (d_cls) {
-            float sp, gp;
-            (void)cce_row(y, p, K, sp, gp);
-            // dL/dp_j = g_j / sum - (sum_k g_k p_k) / sum^2
-            const float tail = gp / (sp * sp);
-            for (int k = 0; k < K; ++k) {
-                const float q = p[k] / sp;
-                const float qc = fminf(fmaxf(q, KERAS_EPS), 1.0f - KERAS_EPS);
-                const bool pass = q >= KERAS_EPS && q <= 1.0f - KERAS_EPS;
-                const float g = pass ? -y[k] / qc : 0.0f;
-                d_cls[row * K + k] = w_cls * (g / sp - tail);
+        bool first = true;
+        for (int j = i; j < S; ++j) {
+            if (j != i && tindex[(size_t)b * S + j] != r) continue;
+            const float* y = label + ((size_t)b * S + j) * K;
+            if (d_cls) {
+                float sp, gp;
+                (void)cce_row(y, p, K, sp, gp);
+                // dL/dp_j = g_j / sum - (sum_k g_k p_k) / sum^2
+                const float tail = gp / (sp * sp);
+                for (int k = 0; k < K; ++k) {
+                    const float q = p[k] / sp;
+                    const float qc = fminf(fmaxf(q, KERAS_EPS), 1.0f - KERAS_EPS);
+                    const bool pass = q >= KERAS_EPS && q <= 1.0f - KERAS_EPS;
+                    const float g = pass ? -y[k] / qc : 0.0f;
+                    const float v = w_cls * (g / sp - tail);
+                    if (first) d_cls[row * K + k] = v; else d_cls[row * K + k] += v;
+                }
             }
-        }
-        if (d_reg && gt_mask[(size_t)b * S + i] != 0) {
-            const int c = argmax_row(y, K);
-            const float4 t = reinterpret_cast<const float4*>(gt_coord)[(size_t)b * S + i];
-            const float4 q = reinterpret_cast<const float4*>(reg)[row * K + c];
-            float4 g;
-            (void)huber(fminf(fmaxf(t.x, -100.f), 100.f), q.x, g.x);
-            (void)huber(fminf(fmaxf(t.y, -100.f), 100.f), q.y, g.y);
-            (void)huber(fminf(fmaxf(t.z, -100.f), 100.f), q.z, g.z);
-            (void)huber(fminf(fmaxf(t.w, -100.f), 100.f), q.w, g.w);
-            g.x *= w_reg; g.y *= w_reg; g.z *= w_reg; g.w *= w_reg;
-            reinterpret_cast<float4*>(d_reg)[row * K + c] = g;
+            if (d_reg && gt_mask[(size_t)b * S + j] != 0) {
+                const int c = argmax_row(y, K);
+                const float4 t = reinterpret_cast<const float4*>(gt_coord)[(size_t)b * S + j];
+                const float4 q = reinterpret_cast<const float4*>(reg)[row * K + c];
+                float4 g;
+                (void)huber(fminf(fmaxf(t.x, -100.f), 100.f), q.x, g.x);
+                (void)huber(fminf(fmaxf(t.y, -100.f), 100.f), q.y, g.y);
+                (void)huber(fminf(fmaxf(t.z, -100.f), 100.f), q.z, g.z);
+                (void)huber(fminf(fmaxf(t.w, -100.f), 100.f), q.w, g.w);
+                // d_reg was zero-filled by this call: adding keeps repeated (row, class) pairs
+                float4* dst = reinterpret_cast<float4*>(d_reg) + (row * K + c);
+                float4 acc = *dst;
+                acc.x += g.x * w_reg; acc.y += g.y * w_reg; acc.z += g.z * w_reg; acc.w += g.w * w_reg;
+                *dst = acc;
+            }
+            first = false;
         }
     }
 }

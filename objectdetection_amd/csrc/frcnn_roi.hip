@@ -888,6 +888,12 @@ roi_fwd_generic_kernel(const float* __restrict__ fmap, int H, int W, int C, long
     }
 }
 
+// winner bytes of a plain crop (pool 1: the only sample of each window is sample 0)
+__global__ void __launch_bounds__(256) roi_zero_winner_kernel(uint32_t* __restrict__ p, size_t n4) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) p[i] = 0u;
+}
+
 // ---- backward: gather formulation.  Workgroup = one feature cell (b,y,x);
 // thread = float4 of channels.  Every RoI of the image is visited in order;
 // for each, the (at most a few) samples whose bilinear footprint touches the
@@ -1209,7 +1215,15 @@ extern "C" int frcnn_roi_crop_pool_fwd(const float* fmap, int B, int H, int W, i
     FRCNN_LAUNCH((roi_fwd_stage_kernel<P, WN>), g3, b3, 0, st, fmap, H, W, C, (long long)sb,    \
                  (long long)sh, (long long)sw, rb, R, crop_h, crop_w, ngrp, nsub, out, winner)
         if (pool == 2) { if (winner) FRCNN_WALK(2, true); else FRCNN_WALK(2, false); }
-        else           { FRCNN_WALK(1, false); }
+        else {
+            FRCNN_WALK(1, false);
+            if (winner) {       // C % 64 == 0 and winner is 4-byte aligned here: whole words
+                const size_t n4 = (size_t)B * R * crop_h * crop_w * C / 4;
+                const size_t want = (n4 + 255) / 256;
+                FRCNN_LAUNCH(roi_zero_winner_kernel, dim3((unsigned)(want < 8192 ? want : 8192)),
+                             dim3(256), 0, st, reinterpret_cast<uint32_t*>(winner), n4);
+            }
+        }
 #undef FRCNN_WALK
     } else if (fast) {
         if (pool == 2)

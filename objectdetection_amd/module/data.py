@@ -92,6 +92,11 @@ def making_frcnn_input(gt_box: torch.Tensor, label: torch.Tensor, fmap: torch.Te
     gt_coord2 [B,S,4], proposed [B,R,4], tindex [B,S].  With fuse_pool=True
     crop_fmap is the 2x2-max-pooled [B,R,7,7,C] tensor (the head's first layer,
     module/model.py:30, fused into the crop).
+
+    Sampling is per image for every batch size.  The reference samples per image only for
+    B == 2 (data.py:266-298); its else branch (data.py:300-316), taken for any other B, draws
+    one joint list over the whole [B,R] tensor, caps the positives at 32 in total and returns
+    [1,128].  For B == 1 the two agree; the joint branch for B >= 3 is not reproduced.
     """
     if anchor_box is None:
         raise ValueError("anchor_box is required (the reference reads an undefined global here)")

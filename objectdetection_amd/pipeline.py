@@ -167,6 +167,8 @@ class RegionProposalPath:
             prop.wait_event(ready)
             if self._calls > self.depth:
                 prop.wait_event(ev[4])
+        elif inputs_ready is not None:
+            main.wait_event(ready)                     # inputs may come from another stream
         if self.train:
             G = gt.shape[1]
             ss = self.side.cuda_stream

@@ -779,11 +779,13 @@ def rpn_loss(pred_obj, pred_reg, pos, label, reg_gt):
     hv, hg = loss_bbr(reg_gt.reshape(-1, 4)[is_pos], pred_reg[bi, y, x, a][is_pos])
     P = int(is_pos.sum())
     reg = hv.sum(dtype=np.float64) / (4 * P) if P else 0.0
+    # the mini-batch can hold one (y,x,a) twice (a negative's position is a rank in the
+    # valid-anchor list, module/data.py:108-118): the gradient of a gather accumulates
     d_obj = np.zeros(pred_obj.shape, np.float64)
-    d_obj[bi, y, x, a] = 2.0 * g / (B * S)
+    np.add.at(d_obj, (bi, y, x, a), 2.0 * g / (B * S))
     d_reg = np.zeros(pred_reg.shape, np.float64)
     if P:
-        d_reg[bi[is_pos], y[is_pos], x[is_pos], a[is_pos]] = hg / (4.0 * P)
+        np.add.at(d_reg, (bi[is_pos], y[is_pos], x[is_pos], a[is_pos]), hg / (4.0 * P))
     return (cls, reg, 2.0 * cls + reg), d_obj, d_reg
 
 
@@ -804,10 +806,10 @@ def head_loss(cls_prob, reg, tindex, label, gt_mask, gt_coord):
     P = int(m.sum())
     lreg = hv.sum(dtype=np.float64) / (4 * P) if P else 0.0
     d_cls = np.zeros(cls_prob.shape, np.float64)
-    d_cls[bi, r] = 2.0 * dp / (B * S)
+    np.add.at(d_cls, (bi, r), 2.0 * dp / (B * S))                   # repeated rows accumulate
     d_reg = np.zeros(reg.shape, np.float64)
     if P:
-        d_reg[bi[m], r[m], c[m]] = hg / (4.0 * P)
+        np.add.at(d_reg, (bi[m], r[m], c[m]), hg / (4.0 * P))
     return (cls, lreg, 2.0 * cls + lreg), d_cls, d_reg
 
 

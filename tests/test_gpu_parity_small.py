@@ -178,6 +178,26 @@ def test_roi_crop_pool_exact(dev, ref_inputs, C):
     np.testing.assert_array_equal(out2.cpu().numpy(), ro[:, :50])
 
 
+def test_plain_crop_with_winner_is_zero(dev):
+    """pool = 1: every window has one sample, so the winner bytes are 0 on every kernel path
+    (C = 64: staged walk; 32: channels-last; 6: any-stride)."""
+    from objectdetection_amd import ops
+    rng = np.random.default_rng(12)
+    for C in (64, 32, 6):
+        fm = rng.standard_normal((2, 9, 11, C)).astype(np.float32)
+        y1, x1 = rng.uniform(0, 0.6, (2, 7)), rng.uniform(0, 0.6, (2, 7))
+        prop = np.stack([y1, x1, y1 + 0.3, x1 + 0.35], -1).astype(np.float32)
+        out, win = ops.roi_crop_pool_fwd(T(fm, dev), T(prop, dev), (6, 6), 1, want_winner=True)
+        win.fill_(7)
+        del win
+        out, win2 = ops.roi_crop_pool_fwd(T(fm, dev), T(prop, dev), (6, 6), 1, want_winner=True)
+        # a fresh tensor may reuse the block just filled with 7: zeros prove the call wrote it
+        ro, ra = O.roi_crop_pool(fm, prop, (6, 6), 1)
+        np.testing.assert_array_equal(out.cpu().numpy(), ro)
+        assert not win2.cpu().numpy().any()
+        assert not ra.any()
+
+
 def test_roi_backward_exact(dev):
     from objectdetection_amd import ops
     d = O.synth_inputs(seed=3, B=1, H=9, W=11, A=1, C=8, G=4)

@@ -78,3 +78,38 @@ def test_graph_replay_equals_run(dev, train):
         torch.cuda.synchronize()
         for k, v in got.items():
             assert torch.equal(v, getattr(path, k)), k
+
+
+def test_inputs_ready_from_another_stream_depth1(dev):
+    """Inputs produced on a third stream: with depth 1 the caller's stream itself waits for the
+    `inputs_ready` event before the proposal stage reads them."""
+    from objectdetection_amd.config import PathConfig
+    from objectdetection_amd.pipeline import RegionProposalPath
+    g = np.load(os.path.join(GOLD, "ref_small.npz"), allow_pickle=False)
+    cfg = PathConfig(H=int(g["H"]), W=int(g["W"]), scales=tuple(g["scales"].tolist()),
+                     G=int(g["G"]), pre_k=int(g["pre_k"]), post_n=int(g["post_n"]))
+    B, C = g["gt"].shape[0], int(g["C"])
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(5)
+    src = [torch.rand((B, cfg.H, cfg.W, C), generator=gen, device=dev),
+           torch.rand((B, cfg.H, cfg.W, cfg.A), generator=gen, device=dev),
+           torch.randn((B, cfg.H, cfg.W, 4 * cfg.A), generator=gen, device=dev) * 0.5]
+    path = RegionProposalPath(cfg, B, C, dev, train=False)
+    path.run(*src)
+    torch.cuda.synchronize()
+    want = {k: getattr(path, k).clone() for k in KEYS[:5]} | {"pooled": path.pooled.clone()}
+    ins = [torch.zeros_like(t) for t in src]
+    big = torch.empty(64 << 20, device=dev)
+    torch.cuda.synchronize()
+    producer = torch.cuda.Stream(dev)
+    ev = torch.cuda.Event()
+    with torch.cuda.stream(producer):
+        for _ in range(20):                                   # keeps the producer busy for a while
+            big.mul_(1.0001)
+        for t, s in zip(ins, src):
+            t.copy_(s)
+        ev.record(producer)
+    path.run(*ins, inputs_ready=ev)
+    torch.cuda.synchronize()
+    for k, v in want.items():
+        assert torch.equal(v, getattr(path, k)), k

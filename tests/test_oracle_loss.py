@@ -3,6 +3,7 @@ Keras formulas, values and autograd gradients.  Parity unpinned (no TensorFlow h
 formulas are tf.keras.backend.binary_crossentropy / categorical_crossentropy (TF 2.3, eager
 path) and Faster_RCNN/module/loss.py:9-14."""
 import numpy as np
+import pytest
 import torch
 
 from oracle import frcnn_oracle as O
@@ -10,7 +11,7 @@ from oracle import frcnn_oracle as O
 EPS = 1e-7
 
 
-def _inputs(seed=0, B=3, H=5, W=6, A=4, S=32, R=40, K=7):
+def _inputs(seed=0, B=3, H=5, W=6, A=4, S=32, R=40, K=7, dup=False):
     rng = np.random.default_rng(seed)
     pred_obj = rng.random((B, H, W, A), dtype=np.float32)
     pred_reg = rng.normal(size=(B, H, W, A, 4)).astype(np.float32) * 2
@@ -30,6 +31,19 @@ def _inputs(seed=0, B=3, H=5, W=6, A=4, S=32, R=40, K=7):
     onehot = np.eye(K, dtype=np.float32)[cls]
     gt_mask = (cls != K - 1).astype(np.int32)
     gt_coord = rng.normal(size=(B, S, 4)).astype(np.float32) * 60    # some beyond +-100
+    if dup:
+        # repeated gather positions, as the RPN mini-batch really holds them (a negative's
+        # position is a rank in the valid-anchor list and can equal a positive's anchor id,
+        # module/data.py:108-118): one anchor as label 1 and label 0, one anchor twice as
+        # label 1, one three times; one proposal row twice with different classes
+        for b in range(B):
+            pos[b, 5] = pos[b, 2]; label[b, 2], label[b, 5] = 1.0, 0.0
+            pos[b, 9] = pos[b, 7]; label[b, 7] = label[b, 9] = 1.0
+            pos[b, 20] = pos[b, 11]; pos[b, 30] = pos[b, 11]
+            tindex[b, 6] = tindex[b, 3]; cls[b, 3], cls[b, 6] = 0, 1
+            tindex[b, 12] = tindex[b, 10]; cls[b, 10] = cls[b, 12] = 2
+        onehot = np.eye(K, dtype=np.float32)[cls]
+        gt_mask = (cls != K - 1).astype(np.int32)
     return dict(pred_obj=pred_obj, pred_reg=pred_reg, pos=pos, label=label, reg_gt=reg_gt,
                 cls_prob=cls_prob, reg=reg, tindex=tindex, onehot=onehot, gt_mask=gt_mask,
                 gt_coord=gt_coord)
@@ -53,8 +67,9 @@ def test_bce_known_values():
     assert g[2] == 0                                                # outside the clip range
 
 
-def test_rpn_loss_matches_torch_autograd():
-    d = _inputs()
+@pytest.mark.parametrize("dup", [False, True])
+def test_rpn_loss_matches_torch_autograd(dup):
+    d = _inputs(dup=dup)
     (cls, reg, tot), d_obj, d_reg = O.rpn_loss(d["pred_obj"], d["pred_reg"], d["pos"], d["label"],
                                                d["reg_gt"])
     po = torch.tensor(d["pred_obj"], dtype=torch.float64, requires_grad=True)
@@ -76,8 +91,9 @@ def test_rpn_loss_matches_torch_autograd():
     np.testing.assert_allclose(d_reg, pr.grad.numpy(), rtol=1e-5, atol=1e-9)
 
 
-def test_head_loss_matches_torch_autograd():
-    d = _inputs(1)
+@pytest.mark.parametrize("dup", [False, True])
+def test_head_loss_matches_torch_autograd(dup):
+    d = _inputs(1, dup=dup)
     (cls, reg, tot), d_cls, d_reg = O.head_loss(d["cls_prob"], d["reg"], d["tindex"], d["onehot"],
                                                 d["gt_mask"], d["gt_coord"])
     cp = torch.tensor(d["cls_prob"], dtype=torch.float64, requires_grad=True)
@@ -107,3 +123,17 @@ def test_no_positive_gives_zero_regression_loss():
     (cls, reg, tot), _, d_reg = O.rpn_loss(d["pred_obj"], d["pred_reg"], d["pos"], d["label"],
                                            d["reg_gt"])
     assert reg == 0.0 and tot == 2 * cls and not d_reg.any()
+
+
+def test_rpn_minibatch_really_repeats_anchors():
+    """patch_batch on the 31x31x9 grid: some images list one (y,x,a) as a positive and as a
+    negative (quirk of module/data.py:108-118), so the gradient scatter must accumulate."""
+    a = O.make_anchor()
+    n_dup = 0
+    for seed in range(12):
+        d = O.synth_inputs(seed=seed, B=1, H=31, W=31, A=9, C=4, G=42, with_fmap=False)
+        out = O.patch_batch(dict(image=None, bbox=d["gt"][0], label=d["label"][0]), a, seed=seed)
+        pos = out[5]
+        lin = (pos[:, 0] * 31 + pos[:, 1]) * 9 + pos[:, 2]
+        n_dup += len(lin) - len(np.unique(lin))
+    assert n_dup > 0
