@@ -36,6 +36,7 @@ extern "C" {
 #define FRCNN_E_WORKSPACE  -2   /* workspace missing or too small              */
 #define FRCNN_E_LAUNCH     -3   /* hipGetLastError() != hipSuccess after launch */
 #define FRCNN_E_UNSUPPORTED -4  /* size beyond what the kernels are built for  */
+#define FRCNN_E_STATIC_LIMIT -5 /* needs more than the built-in scratch array holds */
 
 /* flag bits written by frcnn_iou_assign */
 #define FRCNN_F_VALID     1u    /* all four anchor coords strictly in (0,1)    */
@@ -150,6 +151,23 @@ size_t frcnn_nms_workspace_bytes(int B, int K, int post_n);
 int frcnn_nms(const float* boxes, int B, int K, float iou_threshold, int post_n,
               float* proposed, int32_t* keep_pos, int32_t* keep_count,
               void* workspace, size_t workspace_bytes, frcnn_stream_t stream);
+
+/* The same NMS for callers that cannot allocate device memory (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.
+ * Same arguments, results and kernels as frcnn_nms, minus the workspace: the masks, the kept
+ * index list and the counters live in a device array built into the library
+ * (FRCNN_NMS_STATIC_BYTES per GPU, held until the process ends).  The call allocates and frees
+ * nothing.  Returns FRCNN_E_STATIC_LIMIT when frcnn_nms_workspace_bytes(B,K,post_n) exceeds
+ * FRCNN_NMS_STATIC_BYTES (e.g. post_n = 2000: up to 42 images per call; the need does not
+ * depend on K).  Nothing has to be cleared between calls (the first chunk of a call never reads
+ * the array).  All calls on one GPU share the array: calls that overlap on one GPU (two
+ * streams, two threads) race -- order them, or use frcnn_nms with a workspace per stream.
+ * The array's address is looked up on the first call on each device; make that call outside
+ * graph capture. */
+#define FRCNN_NMS_STATIC_BYTES (16u << 20)
+int frcnn_nms_static(const float* boxes, int B, int K, float iou_threshold, int post_n,
+                     float* proposed, int32_t* keep_pos, int32_t* keep_count,
+                     frcnn_stream_t stream);
 
 /* ---- a7 + a8: fused bilinear RoI crop + max-pool, forward --------------------------
  * Replaces tf.image.crop_and_resize(fmap, boxes, box_idx, (crop_h,crop_w)),

@@ -13,7 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FRCNN_HIP_LIB") or os.path.join(_HERE, "lib", "libfrcnn_hip.so")
 
 OK = 0
-E_BADARG, E_WORKSPACE, E_LAUNCH, E_UNSUPPORTED = -1, -2, -3, -4
+E_BADARG, E_WORKSPACE, E_LAUNCH, E_UNSUPPORTED, E_STATIC_LIMIT = -1, -2, -3, -4, -5
+NMS_STATIC_BYTES = 16 << 20
 F_VALID, F_POSITIVE, F_NEGATIVE = 1, 2, 4
 S_OK, S_SHORT_BATCH = 0, 1
 
@@ -51,6 +52,7 @@ _SIGS = {
     "frcnn_topk_sort": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "frcnn_nms_workspace_bytes": (_sz, [_i, _i, _i]),
     "frcnn_nms": (_i, [_p, _i, _i, _f, _i, _p, _p, _p, _p, _sz, _p]),
+    "frcnn_nms_static": (_i, [_p, _i, _i, _f, _i, _p, _p, _p, _p]),
     "frcnn_roi_crop_pool_fwd": (_i, [_p, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _p, _i, _i, _i,
                                      _i, _p, _p, _p]),
     "frcnn_roi_crop_pool_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),

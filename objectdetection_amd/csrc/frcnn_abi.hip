@@ -10,6 +10,7 @@ extern "C" const char* frcnn_status_string(int status) {
         case FRCNN_E_WORKSPACE: return "workspace missing or too small";
         case FRCNN_E_LAUNCH: return "kernel launch failed";
         case FRCNN_E_UNSUPPORTED: return "size not supported by this build";
+        case FRCNN_E_STATIC_LIMIT: return "needs more scratch than the built-in array holds (FRCNN_NMS_STATIC_BYTES)";
         default: return "unknown status";
     }
 }

@@ -2,6 +2,7 @@
 // sort, fused box decode) and greedy NMS (wave-ballot bitmask kernel followed
 // by a one-wave scan per image).  gfx950, wave64.  -ffp-contract=off.
 #include "frcnn_common.h"
+#include <atomic>
 
 namespace frcnn {
 
@@ -375,19 +376,13 @@ extern "C" size_t frcnn_nms_workspace_bytes(int B, int K, int post_n) {
            align256((size_t)B * 8);
 }
 
-extern "C" int frcnn_nms(const float* boxes, int B, int K, float iou_threshold, int post_n,
-                         float* proposed, int32_t* keep_pos, int32_t* keep_count, void* workspace,
-                         size_t workspace_bytes, frcnn_stream_t stream) {
-    if (!boxes || !proposed || B <= 0 || K <= 0 || post_n <= 0) return FRCNN_E_BADARG;
-    if (!(iou_threshold >= 0.0f)) return FRCNN_E_BADARG;
-    if (!workspace || workspace_bytes < frcnn_nms_workspace_bytes(B, K, post_n))
-        return FRCNN_E_WORKSPACE;
-    if ((reinterpret_cast<uintptr_t>(workspace) & 7u) != 0) return FRCNN_E_BADARG;
+// the chunk loop both entry points share; `ws` holds frcnn_nms_workspace_bytes(B,K,post_n) bytes
+static int nms_launch(const float* boxes, int B, int K, float iou_threshold, int post_n,
+                      float* proposed, int32_t* keep_pos, int32_t* keep_count, char* ws,
+                      hipStream_t st) {
     const int CB = (K + 63) / 64;
     const int KT = (post_n + 63) / 64;
     if (B > 65535 || (KT + NMS_CW + 3) / 4 > 0x7FFFFFFF) return FRCNN_E_UNSUPPORTED;
-    hipStream_t st = (hipStream_t)stream;
-    char* ws = reinterpret_cast<char*>(workspace);
     unsigned long long* maskK = reinterpret_cast<unsigned long long*>(ws);
     ws += nms_maskk_bytes(B, post_n);
     unsigned long long* maskD = reinterpret_cast<unsigned long long*>(ws);
@@ -411,4 +406,47 @@ extern "C" int frcnn_nms(const float* boxes, int B, int K, float iou_threshold, 
                      keep_count);
     }
     return FRCNN_OK;
+}
+
+extern "C" int frcnn_nms(const float* boxes, int B, int K, float iou_threshold, int post_n,
+                         float* proposed, int32_t* keep_pos, int32_t* keep_count, void* workspace,
+                         size_t workspace_bytes, frcnn_stream_t stream) {
+    if (!boxes || !proposed || B <= 0 || K <= 0 || post_n <= 0) return FRCNN_E_BADARG;
+    if (!(iou_threshold >= 0.0f)) return FRCNN_E_BADARG;
+    if (!workspace || workspace_bytes < frcnn_nms_workspace_bytes(B, K, post_n))
+        return FRCNN_E_WORKSPACE;
+    if ((reinterpret_cast<uintptr_t>(workspace) & 7u) != 0) return FRCNN_E_BADARG;
+    return nms_launch(boxes, B, K, iou_threshold, post_n, proposed, keep_pos, keep_count,
+                      reinterpret_cast<char*>(workspace), (hipStream_t)stream);
+}
+
+// ---- the allocation-free variant: the NMS workspace is a device array of the code object.
+// Each GPU the library runs on holds its own copy of the array at its own address, found once
+// per device with hipGetSymbolAddress (in host code the array's name is only a stand-in for
+// that lookup, never a device address).
+static __device__ __align__(256) unsigned char nms_static_scratch[FRCNN_NMS_STATIC_BYTES];
+
+constexpr int NMS_STATIC_MAX_DEVICES = 64;
+static std::atomic<void*> nms_static_ptr[NMS_STATIC_MAX_DEVICES];
+
+extern "C" int frcnn_nms_static(const float* boxes, int B, int K, float iou_threshold, int post_n,
+                                float* proposed, int32_t* keep_pos, int32_t* keep_count,
+                                frcnn_stream_t stream) {
+    if (!boxes || !proposed || B <= 0 || K <= 0 || post_n <= 0) return FRCNN_E_BADARG;
+    if (!(iou_threshold >= 0.0f)) return FRCNN_E_BADARG;
+    if (frcnn_nms_workspace_bytes(B, K, post_n) > (size_t)FRCNN_NMS_STATIC_BYTES)
+        return FRCNN_E_STATIC_LIMIT;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= NMS_STATIC_MAX_DEVICES)
+        return FRCNN_E_LAUNCH;
+    void* ws = nms_static_ptr[dev].load(std::memory_order_acquire);
+    if (!ws) {
+        // first call on this device (the device is current): two threads racing here look up
+        // the same address
+        if (hipGetSymbolAddress(&ws, HIP_SYMBOL(nms_static_scratch)) != hipSuccess || !ws)
+            return FRCNN_E_LAUNCH;
+        nms_static_ptr[dev].store(ws, std::memory_order_release);
+    }
+    return nms_launch(boxes, B, K, iou_threshold, post_n, proposed, keep_pos, keep_count,
+                      reinterpret_cast<char*>(ws), (hipStream_t)stream);
 }
