@@ -62,6 +62,29 @@ def algorithmic_bytes_roi(cfg, C, B):
     return per_image * B
 
 
+def verify_last_step(path, cfg, B, C, device, fmap, score, coord, gt, label, seed, image_base,
+                     train, topk):
+    """Outside the timed region: the last timed step's results (two batches in flight) must
+    equal a plain one-batch-at-a-time rerun of the same step bit for bit.  Raises on a
+    mismatch; returns True."""
+    from objectdetection_amd.pipeline import RegionProposalPath
+    torch.cuda.synchronize(device)
+    last = {k: getattr(path, k).clone() for k in ("proposed", "keep_pos", "keep_count")}
+    if train:
+        last["tindex"] = path.tindex.clone()
+    pooled = path.pooled[B // 2].clone()
+    plain = RegionProposalPath(cfg, B, C, device, train=train, depth=1, topk=topk)
+    plain.run(fmap, score, coord, gt, label, seed=seed, image_base=image_base)
+    torch.cuda.synchronize(device)
+    for k, v in last.items():
+        if not torch.equal(v, getattr(plain, k)):
+            raise SystemExit(f"bench: {k} of the last timed step differs from a plain rerun")
+    if not torch.equal(pooled, plain.pooled[B // 2]):
+        raise SystemExit("bench: pooled tensor of the last timed step differs from a plain rerun")
+    del plain
+    return True
+
+
 def cpu_baseline(cfg, fmap, score, coord, gt, label, threads=16, target_s=12.0):
     """The CPU oracle on the same step: C restatement (oracle/frcnn_oracle_c.c, -O3, no
     FMA contraction) for IoU/argmax, top-k, decode, greedy NMS and crop+pool, numpy
@@ -211,6 +234,9 @@ def main():
             if rec.get("batch") == B and rec.get("channels") == C:
                 traffic = rec.get("hbm_bytes_per_launch")
         kept = path.keep_count.float().mean().item()
+        verified = verify_last_step(path, cfg, B, C, device, fmap, score, coord, gt, label,
+                                    seed=100 + args.steps - 1, image_base=rank * B,
+                                    train=not args.inference, topk=args.topk)
         out = {
             "metric": "images/sec (RPN anchor-match+proposal NMS+RoIPool) 600x1000",
             "value": world * B * args.steps / elapsed,
@@ -235,6 +261,7 @@ def main():
                 "batches_in_flight": args.depth,
                 "mean_kept_proposals": kept,
             },
+            "verified": verified,
             "roofline": {
                 "kernel": "roi_fwd_stage_kernel<2,false>",
                 "bound": "hbm",

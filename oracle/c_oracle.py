@@ -72,3 +72,15 @@ def roi_crop_pool(lib, fmap, rois, crop=(14, 14), pool=2, want_winner=True):
     lib.oc_roi_crop_pool(_p(f), H, W, Cc, _p(r), r.shape[0], crop[0], crop[1], pool, _p(out),
                          _p(win) if win is not None else None)
     return out, win
+
+
+def roi_crop_pool_bwd(lib, dY, winner, rois, fmap_hwc, crop=(14, 14), pool=2):
+    """One image: dY / winner [R,ph,pw,C], rois [R,4] -> dF [H,W,C]."""
+    H, W, Cc = fmap_hwc
+    g = np.ascontiguousarray(dY, np.float32)
+    r = np.ascontiguousarray(rois, np.float32).reshape(-1, 4)
+    w = None if winner is None else np.ascontiguousarray(winner, np.uint8)
+    out = np.empty((H, W, Cc), np.float32)
+    lib.oc_roi_crop_pool_bwd(_p(g), _p(w) if w is not None else None, _p(r), r.shape[0], H, W, Cc,
+                             crop[0], crop[1], pool, _p(out))
+    return out

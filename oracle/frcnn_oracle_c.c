@@ -169,3 +169,48 @@ void oc_roi_crop_pool(const float* fmap, int H, int W, int C, const float* rois,
     }
     free(tmp);
 }
+
+/* Adjoint of oc_roi_crop_pool with respect to fmap, one image (absent in the reference: the
+ * crop is under stop_gradient, module/model.py:71).  Same definition as the numpy
+ * roi_crop_pool_bwd: the pooled gradient goes to the recorded winner sample only, an
+ * extrapolated sample passes nothing, dtop = (1-ly)*g, dbot = ly*g, TL += (1-lx)*dtop,
+ * TR += lx*dtop, BL += (1-lx)*dbot, BR += lx*dbot, every cell summing in float32 in the
+ * order RoI ascending, sample (sy,sx) row-major, corner TL,TR,BL,BR -- which a sequential
+ * scatter in exactly that loop order produces.  dY/winner [R,ph,pw,C]; dF [H,W,C] is
+ * overwritten.  winner may be NULL for pool == 1. */
+void oc_roi_crop_pool_bwd(const float* dY, const uint8_t* winner, const float* rois, int R, int H,
+                          int W, int C, int ch, int cw, int pool, float* dF) {
+    const int ph = ch / pool, pw = cw / pool;
+    int ylo[64], yhi[64], yok[64], xlo[64], xhi[64], xok[64];
+    float yfr[64], xfr[64];
+    memset(dF, 0, sizeof(float) * (size_t)H * W * C);
+    for (int r = 0; r < R; ++r) {
+        const float* b = rois + 4 * (size_t)r;
+        for (int s = 0; s < ch; ++s) oc_axis(b[0], b[2], H, ch, s, &ylo[s], &yhi[s], &yfr[s], &yok[s]);
+        for (int s = 0; s < cw; ++s) oc_axis(b[1], b[3], W, cw, s, &xlo[s], &xhi[s], &xfr[s], &xok[s]);
+        for (int sy = 0; sy < ph * pool; ++sy) {
+            if (!yok[sy]) continue;
+            for (int sx = 0; sx < pw * pool; ++sx) {
+                if (!xok[sx]) continue;
+                const int p = sy / pool, q = sx / pool;
+                const int k = (sy % pool) * pool + (sx % pool);
+                const size_t o = (((size_t)r * ph + p) * pw + q) * C;
+                const float ly = yfr[sy], lx = xfr[sx];
+                const float wt = 1.0f - ly, wb = ly, wl = 1.0f - lx, wr = lx;
+                float* tl = dF + ((size_t)ylo[sy] * W + xlo[sx]) * C;
+                float* tr = dF + ((size_t)ylo[sy] * W + xhi[sx]) * C;
+                float* bl = dF + ((size_t)yhi[sy] * W + xlo[sx]) * C;
+                float* br = dF + ((size_t)yhi[sy] * W + xhi[sx]) * C;
+                for (int c = 0; c < C; ++c) {
+                    if (pool > 1 && winner[o + c] != k) continue;
+                    const float g = dY[o + c];
+                    const float dtop = wt * g, dbot = wb * g;
+                    tl[c] += wl * dtop;
+                    tr[c] += wr * dtop;
+                    bl[c] += wl * dbot;
+                    br[c] += wr * dbot;
+                }
+            }
+        }
+    }
+}
