@@ -182,6 +182,23 @@ int frcnn_roi_crop_pool_fwd(const float* fmap, int B, int H, int W, int C,
                             const float* rois, int R, int crop_h, int crop_w, int pool,
                             float* out, uint8_t* winner, frcnn_stream_t stream);
 
+/* The same forward with a caller-provided workspace of frcnn_roi_fwd_workspace_bytes(B,R) bytes
+ * (272 per RoI, 16-byte aligned, contents on entry do not matter), for the band-resident
+ * kernel: a workgroup keeps a band of one image's feature rows for 32 channels in LDS and
+ * serves every RoI of the image from there, so the feature map enters each compute unit once
+ * instead of once per RoI (module/model.py:53-55 and :30 as above; same results bit for bit).
+ * Opt-in: taken only when the environment variable FRCNN_ROI_BAND_MIN_WG = n is set, the call
+ * has at least n workgroups (B * C/32 * bands), the layout is channels-last with C % 32 == 0 and
+ * crop <= 16 x 16; every other call is forwarded to frcnn_roi_crop_pool_fwd, so the entry
+ * point accepts whatever that one accepts (on the 600x1000 workload the per-RoI kernel is the
+ * faster one: 4.0 ms against 4.6 ms at B = 64). */
+size_t frcnn_roi_fwd_workspace_bytes(int B, int R);
+int frcnn_roi_crop_pool_fwd_ws(const float* fmap, int B, int H, int W, int C,
+                               int64_t sb, int64_t sh, int64_t sw, int64_t sc,
+                               const float* rois, int R, int crop_h, int crop_w, int pool,
+                               float* out, uint8_t* winner, void* workspace,
+                               size_t workspace_bytes, frcnn_stream_t stream);
+
 /* ---- a13: adjoint of a7 + a8 ---------------------------------------------------------
  * The reference never differentiates the crop (stop_gradient,
  * Faster_RCNN/module/model.py:71); this is the exact adjoint, atomic-free: each

@@ -18,24 +18,6 @@ struct AxisGeom {
     int ok[ROI_MAX_CROP];      // 0 -> extrapolated (output 0)
 };
 
-// geometry of sample s along one axis; c1,c2 box corners, dim image size,
-// n crop size.
-__device__ __forceinline__ void axis_sample(float c1, float c2, int dim, int n, int s, int& lo,
-                                            int& hi, float& frac, int& ok) {
-    float in;
-    if (n > 1) {
-        const float scale = ((c2 - c1) * (float)(dim - 1)) / (float)(n - 1);
-        in = c1 * (float)(dim - 1) + (float)s * scale;
-    } else {
-        in = (float)(0.5 * (double)(c1 + c2) * (double)(dim - 1));
-    }
-    ok = (in >= 0.0f && in <= (float)(dim - 1));      // NaN -> extrapolated
-    const float f = floorf(in), c = ceilf(in);
-    frac = in - f;
-    lo = ok ? (int)f : 0;
-    hi = ok ? (int)c : 0;
-}
-
 __device__ __forceinline__ void fill_geom(AxisGeom& gy, AxisGeom& gx, float4 box, int H, int W,
                                           int ch, int cw) {
     const int t = threadIdx.x;

@@ -1,0 +1,476 @@
+// Fused bilinear RoI crop + max-pool, forward, "band-resident" formulation for batches.
+//
+// What limits a per-RoI kernel on this chip is the vector-memory path of a CU (64 B/clk): a
+// RoI's samples touch several times more feature bytes than the RoI produces, and every wave
+// fetches them again.  Here the feature map enters a CU once: a workgroup owns (image,
+// 32-channel group, band of feature rows), copies its band into LDS (up to 160 KB) and then
+// serves EVERY RoI of the image from there; its 16 waves take the RoIs round-robin.  The only
+// vector-memory traffic left is the pooled output (128 B per bin and group) and a 272-byte
+// descriptor per RoI and workgroup.
+//
+// Bands overlap by the largest number of rows an output row of an in-image box can span, so
+// every output row lies wholly inside one band; that band's workgroup produces it.  Output rows
+// that fit no band (boxes reaching beyond the image, so that samples are further apart) are
+// produced by band 0's workgroups straight from global memory.
+//
+// The per-RoI geometry (tf.image.crop_and_resize's sample coordinates, module/model.py:54) is
+// computed once per RoI by a small kernel into the descriptor: per sample row the two feature
+// rows, the weight and what the walk does with its two lerped-row registers (reuse both /
+// shift / read both / extrapolated row), per sample column the two cells and the weight, per
+// output row its band.  The main kernel's row loop is unrolled over the sample rows, so the
+// loop control is a handful of scalar instructions per row.
+//
+// Arithmetic and its order are those of frcnn_roi.hip (top = TL + (TR-TL)*lx; bottom likewise;
+// out = top + (bottom-top)*ly; first maximum wins).  gfx950, wave64, -ffp-contract=off.
+#include "frcnn_common.h"
+#include <cstddef>
+#include <cstdlib>
+
+namespace frcnn {
+
+constexpr int BD_MAXCROP = 16;                 // samples per axis
+constexpr int BD_CG = 32;                      // channels per workgroup
+constexpr int BD_CELL = BD_CG * 4;             // bytes of one cell's channel group
+constexpr int BD_WAVES = 16;
+constexpr int BD_RING = 8;                     // descriptors a wave keeps in LDS at a time
+constexpr int BD_ENTRY = 256;                  // bytes of a descriptor's y and x parts
+constexpr int BD_HDR = 16;                     // bytes of a ring header {roi, rows, rows_direct}
+constexpr int BD_LDS_TOTAL = 160 * 1024;
+constexpr int BD_LDS_RING = BD_WAVES * BD_RING * (BD_ENTRY + BD_HDR);
+constexpr int BD_LDS_BUDGET = BD_LDS_TOTAL - BD_LDS_RING - 64;      // bytes left for the band
+constexpr uint32_t BD_DIRECT = 255, BD_NONE = 254;
+
+// The walk keeps two lerped feature rows in two register sets A and B.  Per sample row the
+// descriptor says what the walk does: REUSE (same floor and ceil rows as the sample row
+// before), SHIFT (its floor row is the previous ceil row: one new row) or BOTH (two new rows),
+// and into which set the ceil row goes (`par`: the sets swap roles whenever exactly one row
+// is added, so nothing is ever moved between registers).
+// y[2s] = lo | hi << 12 | ok << 24 | par << 25 | action << 26, y[2s+1] = weight bits
+// x[2s] = lo | hi << 12 | ok << 24, x[2s+1] = weight bits             (sample column s)
+// band byte p = band of output row p (BD_DIRECT: no band holds it, BD_NONE: no such row)
+constexpr uint32_t BD_REUSE = 0, BD_SHIFT = 1, BD_BOTH = 2;
+struct RoiDesc { uint32_t y[2 * BD_MAXCROP]; uint32_t x[2 * BD_MAXCROP]; uint32_t band[4]; };
+static_assert(sizeof(RoiDesc) == 272 && sizeof(RoiDesc) % 16 == 0, "descriptor layout");
+static_assert(offsetof(RoiDesc, band) == BD_ENTRY, "ring entries are the y and x parts");
+
+__global__ void __launch_bounds__(256)
+roi_band_prep_kernel(const float4* __restrict__ rois, int n_roi, int H, int W, int ch, int cw,
+                     int pool, int nb, int S, int T, RoiDesc* __restrict__ desc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_roi) return;
+    const float4 box = rois[i];
+    RoiDesc* d = desc + i;
+    int rmin = 1 << 30, rmax = -1;
+    uint32_t bandw[4] = {0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu};
+    int st_lo = -1, st_hi = -1;                  // rows of the previous sample row inside the image
+    uint32_t par = 0;                            // set that holds st_hi
+    for (int s = 0; s < BD_MAXCROP; ++s) {
+        int lo = 0, hi = 0, ok = 0;
+        float fr = 0.f;
+        if (s < ch) axis_sample(box.x, box.z, H, ch, s, lo, hi, fr, ok);
+        uint32_t act = BD_BOTH;
+        if (ok) {
+            rmin = min(rmin, min(lo, hi)); rmax = max(rmax, max(lo, hi));
+            if (lo == st_lo && hi == st_hi) act = BD_REUSE;
+            else if (lo == st_hi) { act = BD_SHIFT; par ^= 1u; }
+            st_lo = lo; st_hi = hi;
+        }
+        d->y[2 * s] = (uint32_t)lo | ((uint32_t)hi << 12) | ((uint32_t)ok << 24) | (par << 25) |
+                      (act << 26);
+        d->y[2 * s + 1] = __float_as_uint(fr);
+        if (s < ch && s % pool == pool - 1) {    // output row p is complete
+            const int p = s / pool;
+            uint32_t band = 0;                   // rows of zeros only: band 0 writes them
+            if (rmax >= 0) {
+                const int k = min(rmin / S, nb - 1);
+                band = (rmin >= k * S && rmax < min(k * S + T, H)) ? (uint32_t)k : BD_DIRECT;
+            }
+            bandw[p >> 2] = (bandw[p >> 2] & ~(0xFFu << (8 * (p & 3)))) | (band << (8 * (p & 3)));
+            rmin = 1 << 30; rmax = -1;
+        }
+    }
+    for (int s = 0; s < BD_MAXCROP; ++s) {
+        int lo = 0, hi = 0, ok = 0;
+        float fr = 0.f;
+        if (s < cw) axis_sample(box.y, box.w, W, cw, s, lo, hi, fr, ok);
+        d->x[2 * s] = (uint32_t)lo | ((uint32_t)hi << 12) | ((uint32_t)ok << 24);
+        d->x[2 * s + 1] = __float_as_uint(fr);
+    }
+    for (int j = 0; j < 4; ++j) d->band[j] = bandw[j];
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+struct Quad { f32x2 a, b; };                    // four channels as two packed pairs
+
+// p + (q - p) * w, three packed instructions per pair (each rounds once, in this order)
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ Quad q_lerp(Quad p, Quad q, float w) {
+    const f32x2 w2 = {w, w};
+    Quad r;
+    r.a = p.a + pk_sub(q.a, p.a) * w2;
+    r.b = p.b + pk_sub(q.b, p.b) * w2;
+    return r;
+}
+// dst = p + (q - p) * w, the last instruction writing dst's own registers: a row set that one
+// path of the walk rewrites and another leaves alone then stays in one place (the register
+// allocator otherwise copies both sets in and out of every sample row's code)
+__device__ __forceinline__ void q_lerp_into(Quad& dst, Quad p, Quad q, float w) {
+    const f32x2 w2 = {w, w};
+    const f32x2 ta = pk_sub(q.a, p.a) * w2, tb = pk_sub(q.b, p.b) * w2;
+    asm("v_pk_add_f32 %0, %1, %2" : "+v"(dst.a) : "v"(p.a), "v"(ta));
+    asm("v_pk_add_f32 %0, %1, %2" : "+v"(dst.b) : "v"(p.b), "v"(tb));
+}
+__device__ __forceinline__ Quad q_from(f32x4 t) {
+    Quad r;
+    r.a = __builtin_shufflevector(t, t, 0, 1);
+    r.b = __builtin_shufflevector(t, t, 2, 3);
+    return r;
+}
+__device__ __forceinline__ Quad q_zero() {
+    Quad r;
+    r.a = f32x2{0.f, 0.f}; r.b = r.a;
+    return r;
+}
+__device__ __forceinline__ f32x4 q_pack(Quad v) { return f32x4{v.a.x, v.a.y, v.b.x, v.b.y}; }
+
+__device__ __forceinline__ uint32_t bd_rl(uint32_t v, int lane) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
+}
+__device__ __forceinline__ uint32_t bd_first(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+
+// bits p of the output rows whose band byte equals `want`
+__device__ __forceinline__ uint32_t band_match(uint4 w, uint32_t want) {
+    uint32_t m = 0;
+    const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (((ws[j] >> (8 * t)) & 0xFFu) == want) m |= 1u << (4 * j + t);
+    return m;
+}
+
+// The lerped feature rows a wave holds: two register sets, feature row r lives in set r & 1.
+// A sample row's floor and ceil rows are neighbours, so they never compete for a set, and a
+// row that the next sample row needs again (as its floor row) is already where it belongs:
+// no register moves, whatever the spacing of the sample rows (or their direction).
+struct RowSet { Quad h0, h1; };
+
+template <int POOL, bool WIN>
+__global__ void __launch_bounds__(64 * BD_WAVES)
+roi_fwd_band_kernel(const float* __restrict__ fmap, int H, int W, int C, long long sb, long long sh,
+                    long long sw, const RoiDesc* __restrict__ desc, int R, int ch, int cw,
+                    int ngroup, int S, int T, float* __restrict__ out,
+                    uint8_t* __restrict__ winner) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char band_lds[];
+    const int g = blockIdx.x % ngroup, k = blockIdx.x / ngroup, b = blockIdx.y;
+    const int r0 = k * S, r1 = min(r0 + T, H);
+    const uint32_t rowpitch = (uint32_t)W * BD_CELL;
+    const float* img = fmap + (size_t)b * sb + (size_t)g * BD_CG;
+    // ---- the band: [row][x][32 channels]
+    {
+        const int nparts = (r1 - r0) * W * (BD_CELL / 16);
+        for (int idx = threadIdx.x; idx < nparts; idx += 64 * BD_WAVES) {
+            const int cell = idx >> 3, part = idx & 7;
+            const int row = cell / W, x = cell - row * W;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(img + (size_t)(r0 + row) * sh +
+                                                            (size_t)x * sw + part * 4);
+            *reinterpret_cast<f32x4*>(band_lds + (size_t)row * rowpitch + x * BD_CELL + part * 16) = v;
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 3, quad = lane & 7;
+    const int PH = ch / POOL, PW = cw / POOL;
+    const bool live0 = 2 * q < cw, live1 = 2 * q + 1 < cw;      // this lane's two sample columns
+    const RoiDesc* dimg = desc + (size_t)b * R;
+    const size_t bin_stride = (size_t)C;                         // floats between output columns
+    const uint32_t lds_adj = (uint32_t)quad * 16u - (uint32_t)r0 * rowpitch;
+    // this wave's descriptor ring (private: no barrier, LDS operations of a wave stay in order)
+    unsigned char* ring = band_lds + (size_t)T * rowpitch + (size_t)wave * BD_RING * BD_ENTRY;
+    unsigned char* hdr = band_lds + (size_t)T * rowpitch + (size_t)BD_WAVES * BD_RING * BD_ENTRY +
+                         (size_t)wave * BD_RING * BD_HDR;
+
+#pragma unroll 1
+    for (int base = 0; base < R; base += 64 * BD_WAVES) {
+        // lane l looks at RoI base + 16 l + wave: which of its output rows are this band's
+        const int rc = base + lane * BD_WAVES + wave;
+        uint32_t mine = 0, mine_direct = 0;
+        if (rc < R) {
+            const uint4 bw = *reinterpret_cast<const uint4*>(dimg[rc].band);
+            mine = band_match(bw, (uint32_t)k);
+            if (k == 0) mine_direct = band_match(bw, BD_DIRECT);
+        }
+        unsigned long long todo = __ballot((mine | mine_direct) != 0u);
+#pragma unroll 1
+        while (todo != 0ull) {
+            // ---- next BD_RING descriptors into the ring: piece i = lane + 64 t is part i % 16
+            // of entry i / 16
+            int lpos[BD_RING];
+            int cnt = 0;
+#pragma unroll
+            for (int e = 0; e < BD_RING; ++e) {
+                lpos[e] = 0;
+                if (todo != 0ull) {
+                    lpos[e] = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1ull;
+                    cnt = e + 1;
+                }
+            }
+            {
+                const int sel = lane >> 4, part = lane & 15;
+                uint4 piece[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int e = sel + 4 * t;
+                    const int l = sel == 0 ? lpos[4 * t] : sel == 1 ? lpos[4 * t + 1]
+                                : sel == 2 ? lpos[4 * t + 2] : lpos[4 * t + 3];
+                    piece[t] = make_uint4(0u, 0u, 0u, 0u);
+                    if (e < cnt)
+                        piece[t] = *reinterpret_cast<const uint4*>(
+                            reinterpret_cast<const unsigned char*>(dimg + (base + l * BD_WAVES + wave)) +
+                            part * 16);
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    *reinterpret_cast<uint4*>(ring + (sel + 4 * t) * BD_ENTRY + part * 16) = piece[t];
+                {
+                    // every lane takes part in the shuffles (a shuffle reads active lanes only)
+                    int l = lpos[0];
+#pragma unroll
+                    for (int e = 1; e < BD_RING; ++e) l = lane == e ? lpos[e] : l;
+                    // the rows words live in lane l of `mine` / `mine_direct`
+                    const uint32_t rw = (uint32_t)__shfl((int)mine, l);
+                    const uint32_t rd = (uint32_t)__shfl((int)mine_direct, l);
+                    if (lane < BD_RING)
+                        *reinterpret_cast<uint4*>(hdr + lane * BD_HDR) =
+                            make_uint4((uint32_t)(base + l * BD_WAVES + wave), rw, rd, 0u);
+                }
+            }
+#pragma unroll 1
+            for (int vi = 0; vi < cnt; ++vi) {
+            const uint4 hv = *reinterpret_cast<const uint4*>(hdr + vi * BD_HDR);
+            const int r = (int)bd_first(hv.x);
+            const uint32_t rows = bd_first(hv.y), rows_direct = bd_first(hv.z);
+            const unsigned char* ent = ring + vi * BD_ENTRY;
+            const uint32_t ydv = *reinterpret_cast<const uint32_t*>(ent + (lane & 31) * 4);
+            const uint4 xdv = *reinterpret_cast<const uint4*>(ent + 128 + q * 16);
+            const uint32_t xlo0 = xdv.x & 0xFFFu, xhi0 = (xdv.x >> 12) & 0xFFFu;
+            const uint32_t xlo1 = xdv.z & 0xFFFu, xhi1 = (xdv.z >> 12) & 0xFFFu;
+            const bool ok0 = live0 && ((xdv.x >> 24) & 1u), ok1 = live1 && ((xdv.z >> 24) & 1u);
+            const float fx0 = __uint_as_float(xdv.y), fx1 = __uint_as_float(xdv.w);
+            const bool xall = __all((ok0 || !live0) && (ok1 || !live1));
+            const uint32_t a0 = xlo0 * BD_CELL + lds_adj, a1 = xhi0 * BD_CELL + lds_adj;
+            const uint32_t a2 = xlo1 * BD_CELL + lds_adj, a3 = xhi1 * BD_CELL + lds_adj;
+            float* oroi = out + ((size_t)b * R + r) * (size_t)(PH * PW) * C + (size_t)g * BD_CG + quad * 4;
+            uint8_t* wroi = WIN ? winner + ((size_t)b * R + r) * (size_t)(PH * PW) * C +
+                                      (size_t)g * BD_CG + quad * 4 : nullptr;
+            RowSet sA, sB;
+            sA.h0 = sA.h1 = sB.h0 = sB.h1 = q_zero();
+            Quad best = q_zero();
+            uchar4 arg = make_uchar4(0, 0, 0, 0);
+
+            // one sample row's two samples folded into the running maximum / stored
+            auto fold = [&](int sy, Quad v0, Quad v1) {
+                if (POOL == 1) {
+                    float* o = oroi + ((size_t)sy * PW + 2 * q) * bin_stride;
+                    if (live0) *reinterpret_cast<f32x4*>(o) = q_pack(v0);
+                    if (live1) *reinterpret_cast<f32x4*>(o + bin_stride) = q_pack(v1);
+                    return;
+                }
+                const int ky = sy % POOL;
+                if (WIN) {
+                    const Quad vs[2] = {v0, v1};
+#pragma unroll
+                    for (int kx = 0; kx < 2; ++kx) {
+                        const int kk = ky * POOL + kx;
+                        if (kk == 0) {
+                            best = vs[kx];
+                            arg = make_uchar4(0, 0, 0, 0);
+                        } else {
+                            if (vs[kx].a.x > best.a.x) { best.a.x = vs[kx].a.x; arg.x = kk; }
+                            if (vs[kx].a.y > best.a.y) { best.a.y = vs[kx].a.y; arg.y = kk; }
+                            if (vs[kx].b.x > best.b.x) { best.b.x = vs[kx].b.x; arg.z = kk; }
+                            if (vs[kx].b.y > best.b.y) { best.b.y = vs[kx].b.y; arg.w = kk; }
+                        }
+                    }
+                } else if (ky == 0) {
+                    best.a.x = vmax2(v0.a.x, v1.a.x); best.a.y = vmax2(v0.a.y, v1.a.y);
+                    best.b.x = vmax2(v0.b.x, v1.b.x); best.b.y = vmax2(v0.b.y, v1.b.y);
+                } else {
+                    best.a.x = vmax3(best.a.x, v0.a.x, v1.a.x); best.a.y = vmax3(best.a.y, v0.a.y, v1.a.y);
+                    best.b.x = vmax3(best.b.x, v0.b.x, v1.b.x); best.b.y = vmax3(best.b.y, v0.b.y, v1.b.y);
+                }
+                if (ky == POOL - 1 && q < PW) {
+                    const size_t o = ((size_t)(sy / POOL) * PW + q) * bin_stride;
+                    *reinterpret_cast<f32x4*>(oroi + o) = q_pack(best);
+                    if (WIN) *reinterpret_cast<uchar4*>(wroi + o) = arg;
+                }
+            };
+            auto lds_row = [&](uint32_t row, RowSet& st) {
+                const uint32_t roff = row * rowpitch;                               // uniform
+                const f32x4 c0 = *reinterpret_cast<const f32x4*>(band_lds + (a0 + roff));
+                const f32x4 c1 = *reinterpret_cast<const f32x4*>(band_lds + (a1 + roff));
+                const f32x4 c2 = *reinterpret_cast<const f32x4*>(band_lds + (a2 + roff));
+                const f32x4 c3 = *reinterpret_cast<const f32x4*>(band_lds + (a3 + roff));
+                st.h0 = q_lerp(q_from(c0), q_from(c1), fx0);
+                st.h1 = q_lerp(q_from(c2), q_from(c3), fx1);
+            };
+            bool have = false;                   // the sets hold the previous sample row's rows
+            bool in_band = false;
+#pragma unroll
+            for (int sy = 0; sy < BD_MAXCROP; ++sy) {
+                if (sy < ch) {                                                      // uniform
+                    if (sy % POOL == 0) in_band = (rows >> (sy / POOL)) & 1u;
+                    if (!in_band) {
+                        have = false;
+                    } else {
+                        const uint32_t yw = bd_rl(ydv, 2 * sy);
+                        const float fy = __uint_as_float(bd_rl(ydv, 2 * sy + 1));
+                        Quad v0 = q_zero(), v1 = q_zero();
+                        if ((yw >> 24) & 1u) {
+                            const uint32_t lo = yw & 0xFFFu, hi = (yw >> 12) & 0xFFFu;
+                            const uint32_t act = have ? (yw >> 26) : BD_BOTH;
+                            have = true;
+                            if ((yw >> 25) & 1u) {               // ceil row lives in set A
+                                if (act == BD_BOTH) lds_row(lo, sB);
+                                if (act != BD_REUSE) lds_row(hi, sA);
+                                v0 = q_lerp(sB.h0, sA.h0, fy); v1 = q_lerp(sB.h1, sA.h1, fy);
+                            } else {
+                                if (act == BD_BOTH) lds_row(lo, sA);
+                                if (act != BD_REUSE) lds_row(hi, sB);
+                                v0 = q_lerp(sA.h0, sB.h0, fy); v1 = q_lerp(sA.h1, sB.h1, fy);
+                            }
+                            if (!xall) {
+                                if (!ok0) v0 = q_zero();
+                                if (!ok1) v1 = q_zero();
+                            }
+                        }
+                        fold(sy, v0, v1);
+                    }
+                }
+            }
+
+            // output rows no band holds: every corner straight from global memory
+            if (rows_direct != 0u) {
+                const float* ip = img + quad * 4;
+#pragma unroll 1
+                for (int sy = 0; sy < ch; ++sy) {
+                    if (!((rows_direct >> (sy / POOL)) & 1u)) continue;             // uniform
+                    const uint32_t yw = bd_rl(ydv, 2 * sy);
+                    const float fy = __uint_as_float(bd_rl(ydv, 2 * sy + 1));
+                    Quad v0 = q_zero(), v1 = q_zero();
+                    if ((yw >> 24) & 1u) {
+                        const float* rt = ip + (size_t)(yw & 0xFFFu) * sh;
+                        const float* rb = ip + (size_t)((yw >> 12) & 0xFFFu) * sh;
+                        auto ld = [&](const float* rp, uint32_t x) {
+                            return q_from(*reinterpret_cast<const f32x4*>(rp + (size_t)x * sw));
+                        };
+                        const Quad t0 = q_lerp(ld(rt, xlo0), ld(rt, xhi0), fx0);
+                        const Quad b0 = q_lerp(ld(rb, xlo0), ld(rb, xhi0), fx0);
+                        const Quad t1 = q_lerp(ld(rt, xlo1), ld(rt, xhi1), fx1);
+                        const Quad b1 = q_lerp(ld(rb, xlo1), ld(rb, xhi1), fx1);
+                        v0 = q_lerp(t0, b0, fy);
+                        v1 = q_lerp(t1, b1, fy);
+                        if (!ok0) v0 = q_zero();
+                        if (!ok1) v1 = q_zero();
+                    }
+                    fold(sy, v0, v1);
+                }
+            }
+            }
+        }
+    }
+}
+
+// rows of the bands for an H x W map and crop height ch: every output row of a box inside the
+// image spans at most V + 1 feature rows, bands are T rows every S = T - V rows.
+struct BandPlan { int nb, S, T; bool ok; };
+
+static BandPlan band_plan(int H, int W, int ch, int pool) {
+    BandPlan p{0, 0, 0, false};
+    const long long rowpitch = (long long)W * BD_CELL;
+    const int Tmax = (int)(BD_LDS_BUDGET / rowpitch);
+    if (Tmax < 1) return p;
+    if (Tmax >= H) { p = BandPlan{1, H, H, true}; return p; }
+    // samples of one output row are (pool-1)*scale apart, scale <= (H-1)/(ch-1) inside the image
+    int V = 1;
+    if (pool > 1 && ch > 1) V = (int)(((long long)(pool - 1) * (H - 1) + (ch - 2)) / (ch - 1)) + 1;
+    if (Tmax <= V) return p;
+    const int nb = (H - V + (Tmax - V) - 1) / (Tmax - V);
+    const int T = (H + (nb - 1) * V + nb - 1) / nb;
+    p = BandPlan{nb, T - V, T, true};
+    return p;
+}
+
+}  // namespace frcnn
+
+using namespace frcnn;
+
+static size_t roi_ws_align(size_t v) { return (v + 255) & ~(size_t)255; }
+
+extern "C" size_t frcnn_roi_fwd_workspace_bytes(int B, int R) {
+    if (B <= 0 || R <= 0) return 0;
+    return roi_ws_align((size_t)B * R * sizeof(RoiDesc));
+}
+
+extern "C" int frcnn_roi_crop_pool_fwd_ws(const float* fmap, int B, int H, int W, int C, int64_t sb,
+                                          int64_t sh, int64_t sw, int64_t sc, const float* rois,
+                                          int R, int crop_h, int crop_w, int pool, float* out,
+                                          uint8_t* winner, void* workspace, size_t workspace_bytes,
+                                          frcnn_stream_t stream) {
+    if (!fmap || !rois || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || R <= 0 ||
+        crop_h <= 0 || crop_w <= 0)
+        return FRCNN_E_BADARG;
+    if (pool != 1 && pool != 2) return FRCNN_E_BADARG;
+    if (crop_h % pool || crop_w % pool) return FRCNN_E_BADARG;
+    const bool aligned = sc == 1 && (C % BD_CG) == 0 && (sb % 4) == 0 && (sh % 4) == 0 &&
+                         (sw % 4) == 0 && sb >= 0 && sh >= 0 && sw >= 0 &&
+                         (reinterpret_cast<uintptr_t>(fmap) % 16) == 0 &&
+                         (reinterpret_cast<uintptr_t>(out) % 16) == 0 &&
+                         (!winner || (reinterpret_cast<uintptr_t>(winner) % 4) == 0);
+    const BandPlan plan = band_plan(H, W, crop_h, pool);
+    const int ngroup = C / BD_CG;
+    // The band kernel is opt-in: on the 600x1000 workload (B = 64, C = 512, R = 2000) it takes
+    // 4.6 ms against 4.0 ms for the per-RoI kernel although it issues 40 times fewer vector
+    // loads -- both are bound by instruction issue, not by memory.  FRCNN_ROI_BAND_MIN_WG = n
+    // enables it for calls with at least n workgroups (B * C/32 * bands; 192 fills the chip).
+    long long min_wg = -1;
+    if (const char* e = getenv("FRCNN_ROI_BAND_MIN_WG")) min_wg = atoll(e);
+    const bool band_path = aligned && plan.ok && crop_h <= BD_MAXCROP && crop_w <= BD_MAXCROP &&
+                           H < 4096 && W < 4096 && B <= 65535 &&
+                           min_wg >= 0 && (long long)B * ngroup * plan.nb >= min_wg && !(pool == 1 && winner) &&
+                           workspace && workspace_bytes >= frcnn_roi_fwd_workspace_bytes(B, R) &&
+                           (reinterpret_cast<uintptr_t>(workspace) % 16) == 0;
+    if (!band_path)
+        return frcnn_roi_crop_pool_fwd(fmap, B, H, W, C, sb, sh, sw, sc, rois, R, crop_h, crop_w,
+                                       pool, out, winner, stream);
+    hipStream_t st = (hipStream_t)stream;
+    RoiDesc* desc = reinterpret_cast<RoiDesc*>(workspace);
+    const int n_roi = B * R;
+    FRCNN_LAUNCH(roi_band_prep_kernel, dim3((n_roi + 255) / 256), dim3(256), 0, st,
+                 reinterpret_cast<const float4*>(rois), n_roi, H, W, crop_h, crop_w, pool, plan.nb,
+                 plan.S, plan.T, desc);
+    const size_t lds = (size_t)plan.T * W * BD_CELL + BD_LDS_RING;
+    const dim3 grid((unsigned)(ngroup * plan.nb), (unsigned)B), block(64 * BD_WAVES);
+#define FRCNN_BAND(P, WN)                                                                          \
+    do {                                                                                           \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(roi_fwd_band_kernel<P, WN>),         \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+            return FRCNN_E_LAUNCH;                                                                 \
+        FRCNN_LAUNCH((roi_fwd_band_kernel<P, WN>), grid, block, lds, st, fmap, H, W, C,            \
+                     (long long)sb, (long long)sh, (long long)sw, desc, R, crop_h, crop_w, ngroup, \
+                     plan.S, plan.T, out, winner);                                                 \
+    } while (0)
+    if (pool == 2) { if (winner) FRCNN_BAND(2, true); else FRCNN_BAND(2, false); }
+    else           { FRCNN_BAND(1, false); }
+#undef FRCNN_BAND
+    return FRCNN_OK;
+}

@@ -215,10 +215,18 @@ def nms(boxes: torch.Tensor, iou_threshold: float, post_n: int,
     return proposed, keep, count
 
 
+def roi_fwd_workspace_bytes(B: int, R: int) -> int:
+    return int(lib.frcnn_roi_fwd_workspace_bytes(B, R))
+
+
 def roi_crop_pool_fwd(fmap: torch.Tensor, rois: torch.Tensor, crop: Tuple[int, int] = (14, 14),
-                      pool: int = 2, want_winner: bool = False, out: Optional[torch.Tensor] = None):
+                      pool: int = 2, want_winner: bool = False, out: Optional[torch.Tensor] = None,
+                      workspace: Optional[torch.Tensor] = None,
+                      winner: Optional[torch.Tensor] = None):
     """fmap [B,H,W,C] (any strides; channels-last is the fast layout), rois [B,R,4]
-    -> pooled [B,R,crop_h/pool,crop_w/pool,C] (+ winner u8)."""
+    -> pooled [B,R,crop_h/pool,crop_w/pool,C] (+ winner u8).  With `workspace` (a uint8 tensor
+    of roi_fwd_workspace_bytes(B,R) bytes) the call goes through frcnn_roi_crop_pool_fwd_ws
+    (band-resident kernel when FRCNN_ROI_BAND_MIN_WG enables it, the same kernels otherwise)."""
     f = _dev(fmap, "fmap", torch.float32)
     if f.dim() != 4:
         raise ValueError("fmap must be [B,H,W,C]")
@@ -234,12 +242,20 @@ def roi_crop_pool_fwd(fmap: torch.Tensor, rois: torch.Tensor, crop: Tuple[int, i
         _dev(out, "out", torch.float32)
         if tuple(out.shape) != (B, R, ph, pw, Cc) or not out.is_contiguous():
             raise ValueError("out has the wrong shape or is not contiguous")
-    win = torch.empty((B, R, ph, pw, Cc), dtype=torch.uint8, device=f.device) if want_winner else None
+    win = winner
+    if want_winner and win is None:
+        win = torch.empty((B, R, ph, pw, Cc), dtype=torch.uint8, device=f.device)
     sb, sh, sw, sc = f.stride()
     with torch.cuda.device(f.device):
-        check("frcnn_roi_crop_pool_fwd", lib.frcnn_roi_crop_pool_fwd(
-            _ptr(f), B, H, W, Cc, sb, sh, sw, sc, _ptr(r), R, crop[0], crop[1], pool, _ptr(out),
-            _ptr(win), _stream(f)))
+        if workspace is not None:
+            _dev(workspace, "workspace", torch.uint8)
+            check("frcnn_roi_crop_pool_fwd_ws", lib.frcnn_roi_crop_pool_fwd_ws(
+                _ptr(f), B, H, W, Cc, sb, sh, sw, sc, _ptr(r), R, crop[0], crop[1], pool,
+                _ptr(out), _ptr(win), _ptr(workspace), workspace.numel(), _stream(f)))
+        else:
+            check("frcnn_roi_crop_pool_fwd", lib.frcnn_roi_crop_pool_fwd(
+                _ptr(f), B, H, W, Cc, sb, sh, sw, sc, _ptr(r), R, crop[0], crop[1], pool, _ptr(out),
+                _ptr(win), _stream(f)))
     return out, win
 
 

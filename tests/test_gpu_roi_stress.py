@@ -42,8 +42,21 @@ def _boxes(rng, n, H, W):
     return np.array(out, np.float32)
 
 
-@pytest.mark.parametrize("C,H,W", [(64, 31, 31), (128, 37, 62), (192, 20, 45), (512, 37, 62)])
-def test_roi_forward_stress(dev, C, H, W):
+@pytest.fixture(params=["per_roi", "band"])
+def ws_for(request, monkeypatch):
+    """Both forward entry points: frcnn_roi_crop_pool_fwd (one wave per RoI and slice) and
+    frcnn_roi_crop_pool_fwd_ws with its band kernel forced on at test sizes."""
+    from objectdetection_amd import ops
+    if request.param == "per_roi":
+        return lambda B, R, dev: None
+    monkeypatch.setenv("FRCNN_ROI_BAND_MIN_WG", "1")
+    return lambda B, R, dev: torch.empty(ops.roi_fwd_workspace_bytes(B, R), dtype=torch.uint8,
+                                         device=dev)
+
+
+@pytest.mark.parametrize("C,H,W", [(64, 31, 31), (128, 37, 62), (192, 20, 45), (512, 37, 62),
+                                   (32, 75, 100)])
+def test_roi_forward_stress(dev, ws_for, C, H, W):
     from objectdetection_amd import ops
     lib = c_oracle.load()
     rng = np.random.default_rng(C + H)
@@ -55,7 +68,7 @@ def test_roi_forward_stress(dev, C, H, W):
     rois[0, 2] = [0.2, 0.2, 0.2, 0.2]
     for pool, win in ((2, True), (2, False), (1, False)):
         out, w = ops.roi_crop_pool_fwd(torch.tensor(fm, device=dev), torch.tensor(rois, device=dev),
-                                       (14, 14), pool, want_winner=win)
+                                       (14, 14), pool, want_winner=win, workspace=ws_for(B, R, dev))
         for b in range(B):
             ro, rw = c_oracle.roi_crop_pool(lib, fm[b], rois[b], (14, 14), pool, want_winner=win)
             got = out[b].cpu().numpy()
@@ -65,7 +78,7 @@ def test_roi_forward_stress(dev, C, H, W):
                 np.testing.assert_array_equal(w[b].cpu().numpy(), rw)
 
 
-def test_roi_forward_other_crop_sizes(dev):
+def test_roi_forward_other_crop_sizes(dev, ws_for):
     """crop 16x16 / pool 2 (pooled width 8: two full column groups), 12x12 / pool 1 (three
     groups), 7x7 / pool 1."""
     from objectdetection_amd import ops
@@ -76,7 +89,7 @@ def test_roi_forward_other_crop_sizes(dev):
     rois = _boxes(rng, 300, H, W)[None]
     for crop, pool in (((16, 16), 2), ((12, 12), 1), ((7, 7), 1), ((14, 8), 2)):
         out, _ = ops.roi_crop_pool_fwd(torch.tensor(fm, device=dev), torch.tensor(rois, device=dev),
-                                       crop, pool)
+                                       crop, pool, workspace=ws_for(1, 300, dev))
         ro, _ = c_oracle.roi_crop_pool(lib, fm[0], rois[0], crop, pool, want_winner=False)
         got = out[0].cpu().numpy()
         assert ((got == ro) | (np.isnan(got) & np.isnan(ro))).all(), (crop, pool)

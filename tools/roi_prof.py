@@ -16,22 +16,24 @@ from objectdetection_amd.pipeline import RegionProposalPath  # noqa: E402
 B = int(os.environ.get("ROI_B", "64"))
 REPS = int(os.environ.get("ROI_REPS", "5"))
 WINNER = os.environ.get("ROI_WINNER", "0") == "1"
+BAND = os.environ.get("ROI_BAND", "1") == "1"       # frcnn_roi_crop_pool_fwd_ws (band kernel)
 dev = torch.device("cuda:0")
 cfg = bench.workload_cfg()
 fmap, score, coord, gt, label = bench.make_inputs(cfg, B, 512, dev, 1000)
 path = RegionProposalPath(cfg, B, 512, dev, train=False)
 path.run(fmap, score, coord)
 torch.cuda.synchronize()
+ws = torch.empty(ops.roi_fwd_workspace_bytes(B, cfg.post_n), dtype=torch.uint8, device=dev) if BAND else None
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 ts = []
 for _ in range(REPS):
     ev0.record()
     ops.roi_crop_pool_fwd(fmap, path.proposed, cfg.crop, cfg.pool, want_winner=WINNER,
-                          out=path.pooled)
+                          out=path.pooled, workspace=ws)
     ev1.record()
     torch.cuda.synchronize()
     ts.append(ev0.elapsed_time(ev1))
 alg = bench.algorithmic_bytes_roi(cfg, 512, B)
 best = min(ts)
-print(f"roi fwd B={B}: min {best:.3f} ms  mean {sum(ts)/len(ts):.3f} ms  "
+print(f"roi fwd B={B} band={int(BAND)}: min {best:.3f} ms  mean {sum(ts)/len(ts):.3f} ms  "
       f"{alg/best/1e6:.1f} GB/s algorithmic ({alg/best/1e6/8000*100:.1f}% of 8 TB/s)")

@@ -60,6 +60,45 @@ __global__ void __launch_bounds__(1024) probe_slice16(float* __restrict__ out, i
     }
 }
 
+// workgroup = (image, 32-channel group, band of feature rows), 16 waves, 127 KB of LDS (one per
+// CU); wave w writes RoIs w, w+16, ...: the pooled rows that fall to its band (here: p % 3 ==
+// band), 7 bins x 128 B per store instruction
+__global__ void __launch_bounds__(1024) probe_band32(float* __restrict__ out, int R) {
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = blockIdx.x % 16, band = blockIdx.x / 16, b = blockIdx.y;
+    if (threadIdx.x == 0) lds[0] = 1.f;
+    f32x4 v = {1.f, 2.f, 3.f, (float)lane};
+    const int q = lane >> 3, quad = lane & 7;
+    for (int r = wave; r < R; r += 16) {
+        float* base = out + ((size_t)b * R + r) * (PH * PW) * C + grp * 32 + quad * 4;
+        for (int p = band; p < PH; p += 3)
+            if (q < PW) *reinterpret_cast<f32x4*>(base + (size_t)(p * PW + q) * C) = v;
+    }
+}
+
+void run_band32(float* out, int B, int R) {
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    const int lds = 127 * 1024;
+    CHECK(hipFuncSetAttribute((const void*)probe_band32, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    dim3 grid(48, B), block(1024);
+    probe_band32<<<grid, block, lds>>>(out, R);
+    CHECK(hipDeviceSynchronize());
+    float best = 1e9f;
+    for (int rep = 0; rep < 3; ++rep) {
+        CHECK(hipEventRecord(a));
+        probe_band32<<<grid, block, lds>>>(out, R);
+        CHECK(hipEventRecord(b));
+        CHECK(hipEventSynchronize(b));
+        float ms = 0.f;
+        CHECK(hipEventElapsedTime(&ms, a, b));
+        if (ms < best) best = ms;
+    }
+    const double bytes = (double)B * R * PH * PW * C * 4;
+    printf("%-64s %7.3f ms  %6.2f TB/s\n", "workgroup = image x 32ch group x band, 128 B pieces", best, bytes / best / 1e9);
+}
+
 void run_slice16(float* out, int B, int R) {
     hipEvent_t a, b;
     CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
@@ -113,5 +152,6 @@ int main() {
     run<3>("4 waves per (roi, slice), rows interleaved", out, B, R, 0);
     run<2>("wave = roi x pooled row, 14 KB contiguous", out, B, R, 0);
     run_slice16(out, B, R);
+    run_band32(out, B, R);
     return 0;
 }
