@@ -1,20 +1,28 @@
 #!/usr/bin/env python3
-"""Headline benchmark: images/sec of the fused RPN path (anchor match +
-proposal NMS + RoI crop/pool) on synthetic 600x1000 images.
+"""Headline benchmark: images/sec of the fused RPN path (anchor match + proposal NMS + RoI
+crop/pool) on synthetic images.
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: under torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W [--config 600x1000|ship768] [--global-batch G]
+                  [--mode path|train]
 
-One step = one pass of the whole hot path (RegionProposalPath.run, training
-mode) over `--batch` images per GPU whose inputs are already resident in HBM.
-Images are independent units: rank r works on its own batch, no data-path
-collective; the barrier and the max-over-ranks time are the only communication.
-Rank 0 prints one JSON line.
+One step = one pass of the whole hot path (RegionProposalPath.run, training mode) over the
+images a rank owns, inputs already resident in HBM.  Images are independent units: rank r works
+on its own images, no data-path collective; the barrier and the max-over-ranks time are the only
+communication (`--mode train` adds the backbone / head stand-ins and the gradient all-reduce).
+`--batch B` fixes the images per GPU (weak scaling, the default); `--global-batch G` fixes the
+total and splits it over the ranks (strong scaling: "64 images sharded over 1/2/4/8 GPUs").
+
+With --gpus N > 1 the script expects to run under torch.distributed.run (one rank per GPU).
+Started without a launcher it starts that launcher itself, before anything touches the GPU,
+and relays rank 0's line.  Rank 0 prints one JSON line.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,16 +34,32 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak
 
+WORKLOADS = {
+    # 600x1000 image, VGG16 stride 16 -> 37x62 map, 9 anchors (20,646), G=42, 12k -> 2k NMS at
+    # 0.7, RoI 14 -> 7, C=512
+    "600x1000": dict(cfg=dict(H=37, W=62, scales=(128, 256, 512), ratios=(0.5, 1, 2),
+                              base_w=1000.0, base_h=600.0, G=42, pre_k=12000, post_n=2000,
+                              nms_thr=0.7),
+                     batch=64, gt_side=(0.05, 0.6),
+                     text="600x1000 image -> 37x62x9 = 20,646 anchors, G=42, top-12000 -> NMS 0.7 "
+                          "-> 2000, RoI crop 14 -> pool 7, C=512"),
+    # ship detector (shipdetection/train.py:129-143): 768x768 -> 48x48 map, 12 anchors
+    # (scales 32..256, still divided by 500), up to 50 small boxes, 6k -> 1.5k
+    "ship768": dict(cfg=dict(H=48, W=48, scales=(32, 64, 128, 256), ratios=(0.5, 1, 2),
+                             base_w=500.0, base_h=500.0, G=50, pre_k=6000, post_n=1500,
+                             nms_thr=0.7),
+                    batch=16, gt_side=(0.01, 0.06),
+                    text="768x768 ship image -> 48x48x12 = 27,648 anchors, G=50 small boxes, "
+                         "top-6000 -> NMS 0.7 -> 1500, RoI crop 14 -> pool 7, C=512"),
+}
 
-def workload_cfg():
+
+def workload_cfg(name="600x1000"):
     from objectdetection_amd.config import PathConfig
-    # 600x1000 image, VGG16 stride 16 -> 37x62 map, 9 anchors (20,646), G=42,
-    # 12k -> 2k NMS at 0.7, RoI 14 -> 7, C=512.
-    return PathConfig(H=37, W=62, scales=(128, 256, 512), ratios=(0.5, 1, 2), base_w=1000.0,
-                      base_h=600.0, G=42, pre_k=12000, post_n=2000, nms_thr=0.7)
+    return PathConfig(**WORKLOADS[name]["cfg"])
 
 
-def make_inputs(cfg, B, C, device, seed):
+def make_inputs(cfg, B, C, device, seed, gt_side=(0.05, 0.6)):
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     score = torch.sigmoid(torch.randn((B, cfg.H, cfg.W, cfg.A), generator=g, device=device) * 2.0)
@@ -44,15 +68,30 @@ def make_inputs(cfg, B, C, device, seed):
     rng = np.random.Generator(np.random.PCG64(seed))
     gt = np.zeros((B, cfg.G, 4), np.float32)
     label = np.zeros((B, cfg.G), np.int64)
+    lo, hi = np.log(gt_side[0]), np.log(gt_side[1])
     for b in range(B):
         n = int(rng.integers(1, cfg.G + 1))
         cy, cx = rng.uniform(0.05, 0.95, n), rng.uniform(0.05, 0.95, n)
-        hh = np.exp(rng.uniform(np.log(0.05), np.log(0.6), n))
-        ww = np.exp(rng.uniform(np.log(0.05), np.log(0.6), n))
+        hh = np.exp(rng.uniform(lo, hi, n))
+        ww = np.exp(rng.uniform(lo, hi, n))
         gt[b, :n] = np.clip(np.stack([cy - hh / 2, cx - ww / 2, cy + hh / 2, cx + ww / 2], 1), 0, 1)
         label[b, :n] = rng.integers(0, 20, n)
     return (fmap.contiguous(), score.contiguous(), coord.contiguous(),
             torch.from_numpy(gt).to(device), torch.from_numpy(label).to(device))
+
+
+def clustered_boxes(B, K, device, seed):
+    """Score-ordered candidates in a few tight clusters per image: greedy NMS at 0.7 keeps far
+    fewer than post_n of them, so every chunk of the candidate list is walked."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    nc = 40
+    centre = rng.uniform(0.2, 0.8, (B, nc, 2))
+    half = rng.uniform(0.05, 0.2, (B, nc, 2))
+    which = rng.integers(0, nc, (B, K))
+    c = np.take_along_axis(centre, which[..., None], 1) + rng.normal(0, 0.004, (B, K, 2))
+    h = np.take_along_axis(half, which[..., None], 1) * (1 + rng.normal(0, 0.02, (B, K, 2)))
+    b = np.clip(np.concatenate([c - h, c + h], -1), 0, 1).astype(np.float32)
+    return torch.from_numpy(b).to(device)
 
 
 def algorithmic_bytes_roi(cfg, C, B):
@@ -129,12 +168,114 @@ def cpu_baseline(cfg, fmap, score, coord, gt, label, threads=16, target_s=12.0):
                        f"{os.cpu_count()} logical CPUs")
 
 
+def cpu_baseline_numpy(cfg, fmap, score, coord, gt, label, target_s=12.0):
+    """The op-for-op numpy restatement (oracle/frcnn_oracle.py: the reference's broadcast
+    formulation, sequential greedy NMS, crop then pool) on whole images, one host thread,
+    until about `target_s` seconds have been spent (at least one image)."""
+    from oracle import frcnn_oracle as O
+    a = O.make_anchor(cfg.H, cfg.W, cfg.scales, cfg.ratios, cfg.base_w, cfg.base_h)
+    f, s, c = fmap.cpu().numpy(), score.cpu().numpy(), coord.cpu().numpy()
+    g, l = gt.cpu().numpy(), label.cpu().numpy()
+    n, done = fmap.shape[0], 0
+    t0 = time.perf_counter()
+    while done < n and (done == 0 or time.perf_counter() - t0 < target_s):
+        i = done
+        O.patch_batch(dict(image=None, bbox=g[i], label=l[i]), a, seed=0, image_index=i,
+                      batch=cfg.rpn_batch, max_pos=cfg.rpn_max_pos)
+        pc = O.proposal_creator(s[i:i + 1], c[i:i + 1], a, cfg.pre_k, cfg.post_n, cfg.nms_thr)
+        O.roi_crop_pool(f[i:i + 1], pc["proposed"], cfg.crop, cfg.pool)
+        lab = O.label_proposals(pc["proposed"], g[i:i + 1], l[i:i + 1], cfg.fg_thr, cfg.iou_floor,
+                                cfg.bg_label, cfg.num_classes)
+        O.sample_proposals(lab["p_iou"], seed=0, image_base=i, batch=cfg.head_batch,
+                           max_pos=cfg.head_max_pos, bg_label=cfg.bg_label)
+        done += 1
+    dt = time.perf_counter() - t0
+    return dict(value=done / dt, unit="images/s", cores=1, kind="port",
+                sample=f"{done} images in {dt:.2f} s on one host thread; numpy restatement of the "
+                       f"reference's formulation (oracle/frcnn_oracle.py)")
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launcher_command(n, argv):
+    """The launch the driver uses for N > 1, for a bare `python bench.py --gpus N ...`."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+            os.path.abspath(__file__)] + list(argv)
+
+
+def timed_alone(fn, device, reps=5):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ts = []
+    for _ in range(reps):
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize(device)
+        ts.append(e0.elapsed_time(e1))
+    return float(np.mean(ts[1:]))
+
+
+def kernel_table(path, cfg, B, C, fmap, score, coord, gt, label, device):
+    """Every stage alone on an idle chip (outside the timed region), with its algorithmic
+    bytes (per image: anchors N*16, GT G*16, assignment out N*9, deltas N*16, scores N*4,
+    top-k out K*8 + K*16, feature map H*W*C*4, pooled R*49*C*4) and the fraction of the HBM
+    peak those bytes over that time amount to."""
+    from objectdetection_amd import ops
+    N, K, R, G = cfg.N, cfg.pre_k, cfg.post_n, gt.shape[1]
+    a = path.anchor.reshape(-1, 4)
+    rows = []
+
+    def add(name, fn, nbytes):
+        ms = timed_alone(fn, device)
+        rows.append(dict(name=name, ms_alone=ms, bytes=int(nbytes),
+                         frac=nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS))
+
+    add("iou_assign_kernel", lambda: ops.iou_assign(a, gt, cfg.rpn_pos_thr, cfg.rpn_neg_thr),
+        B * (N * 16 + G * 16 + N * 9))
+    add("rpn_sample_kernel", lambda: ops.rpn_sample(path.anchor, gt, path.best_gt, path.flags,
+                                                    seed=1, batch=cfg.rpn_batch,
+                                                    max_pos=cfg.rpn_max_pos),
+        B * (N * 5 + cfg.rpn_batch * 100))
+    add("topk_sort (ts_* kernels)", lambda: ops.topk(score.reshape(B, -1), K, a, coord, "sort",
+                                                     workspace=path.topk_ws),
+        B * (N * 4 + K * 16 + K * 8 + K * 16))
+    if K <= 16384:
+        add("topk_kernel (LDS radix select)",
+            lambda: ops.topk(score.reshape(B, -1), K, a, coord, "lds"),
+            B * (N * 4 + K * 16 + K * 8 + K * 16))
+    add("nms (mask + scan kernels)", lambda: ops.nms(path.cand, cfg.nms_thr, R, workspace=path.nms_ws),
+        B * (K * 16 + R * 20))
+    add("roi_fwd_stage_kernel<2,false>",
+        lambda: ops.roi_crop_pool_fwd(fmap, path.proposed, cfg.crop, cfg.pool, out=path.pooled),
+        algorithmic_bytes_roi(cfg, C, B))
+    add("label_proposals_kernel", lambda: ops.label_proposals(path.proposed, gt, label, cfg.fg_thr,
+                                                              cfg.iou_floor, cfg.bg_label,
+                                                              cfg.num_classes),
+        B * (R * 16 + G * 24 + R * (8 + 4 + 4 * cfg.num_classes + 16 + 8)))
+    add("sample_proposals_kernel", lambda: ops.sample_proposals(path.p_label, cfg.bg_label, seed=1,
+                                                                batch=cfg.head_batch,
+                                                                max_pos=cfg.head_max_pos),
+        B * (R * 8 + cfg.head_batch * 8))
+    return rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
+    ap.add_argument("--config", default="600x1000", choices=sorted(WORKLOADS))
+    ap.add_argument("--mode", default="path", choices=("path", "train"),
+                    help="path: the hot path alone; train: RPN + head training step around it "
+                         "(stand-in backbone / head, RoI backward, gradient all-reduce)")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="total images per step, split over the ranks (strong scaling)")
     ap.add_argument("--channels", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inference", action="store_true", help="skip the training-only stages")
@@ -144,31 +285,64 @@ def main():
     ap.add_argument("--topk", default="sort", choices=("sort", "lds"))
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend (gloo lets several ranks rehearse on one GPU)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="initialise the process group, reduce one number, print n_gpus and exit "
+                         "(checks the launch path without a GPU)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: become one (nothing has touched the GPU yet) and relay the ranks' output
+        proc = subprocess.run(launcher_command(args.gpus, sys.argv[1:]))
+        raise SystemExit(proc.returncode)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        ndev = torch.cuda.device_count()
-        if args.backend == "nccl":
+        if args.backend == "nccl" and not args.rendezvous_only:
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local))
         else:
-            local = local % max(ndev, 1)
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+            dist.init_process_group("gloo" if args.rendezvous_only else args.backend, rank=rank,
+                                    world_size=world)
+    if args.rendezvous_only:
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps({"n_gpus": world, "rendezvous": "ok", "max_rank_plus_1": t.item()}),
+                  flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
 
+    wl = WORKLOADS[args.config]
+    cfg = workload_cfg(args.config)
+    C = args.channels
+    if args.global_batch is not None:
+        if args.global_batch % world:
+            raise SystemExit("--global-batch must be a multiple of --gpus")
+        B, scaling = args.global_batch // world, "strong"
+    else:
+        B, scaling = args.batch or wl["batch"], "weak"
+
+    if args.mode == "train":
+        from objectdetection_amd.train import bench_train
+        bench_train(args, cfg, wl, B, C, device, dist, rank, world, scaling)
+        return
+
     from objectdetection_amd.pipeline import RegionProposalPath
-    cfg = workload_cfg()
-    B, C = args.batch, args.channels
-    fmap, score, coord, gt, label = make_inputs(cfg, B, C, device, seed=1000 + rank)
+    fmap, score, coord, gt, label = make_inputs(cfg, B, C, device, seed=1000 + rank,
+                                                gt_side=wl["gt_side"])
     path = RegionProposalPath(cfg, B, C, device, train=not args.inference, depth=args.depth,
                               topk=args.topk)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -202,43 +376,41 @@ def main():
     if rank == 0:
         roi_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
         nms_busy_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_nms]))
-        # the NMS alone on an idle chip (outside the timed region): mask + scan launches on the
-        # candidates of the last batch
         from objectdetection_amd import ops
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        alone = []
-        for _ in range(5):
-            e0.record()
-            ops.nms(path.cand, cfg.nms_thr, cfg.post_n, workspace=path.nms_ws)
-            e1.record()
-            torch.cuda.synchronize(device)
-            alone.append(e0.elapsed_time(e1))
-        nms_ms = float(np.mean(alone[1:]))
-        # the RoI kernel alone (inside the step it shares the chip with the next batch's
-        # proposal stage)
-        roi_alone = []
-        for _ in range(4):
-            e0.record()
-            ops.roi_crop_pool_fwd(fmap, path.proposed, cfg.crop, cfg.pool, out=path.pooled)
-            e1.record()
-            torch.cuda.synchronize(device)
-            roi_alone.append(e0.elapsed_time(e1))
-        roi_alone_ms = float(np.mean(roi_alone[1:]))
-        alg = algorithmic_bytes_roi(cfg, C, B)
-        achieved = alg / (roi_ms * 1e-3) / 1e9
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "roi_fwd_traffic.json")
-        if os.path.exists(tf):
-            with open(tf) as fh:
-                rec = json.load(fh)
-            if rec.get("batch") == B and rec.get("channels") == C:
-                traffic = rec.get("hbm_bytes_per_launch")
         kept = path.keep_count.float().mean().item()
         verified = verify_last_step(path, cfg, B, C, device, fmap, score, coord, gt, label,
                                     seed=100 + args.steps - 1, image_base=rank * B,
                                     train=not args.inference, topk=args.topk)
+        # stages alone on an idle chip (outside the timed region)
+        nms_ms = timed_alone(lambda: ops.nms(path.cand, cfg.nms_thr, cfg.post_n,
+                                             workspace=path.nms_ws), device)
+        cl = clustered_boxes(B, cfg.pre_k, device, seed=77)
+        cl_out = ops.nms(cl, cfg.nms_thr, cfg.post_n, workspace=path.nms_ws)
+        nms_cl_ms = timed_alone(lambda: ops.nms(cl, cfg.nms_thr, cfg.post_n,
+                                                workspace=path.nms_ws), device)
+        nms_cl_kept = cl_out[2].float().mean().item()
+        roi_alone_ms = timed_alone(lambda: ops.roi_crop_pool_fwd(fmap, path.proposed, cfg.crop,
+                                                                 cfg.pool, out=path.pooled),
+                                   device, reps=4)
+        kernels = kernel_table(path, cfg, B, C, fmap, score, coord, gt, label, device) \
+            if not args.inference else None
+        alg = algorithmic_bytes_roi(cfg, C, B)
+        achieved = alg / (roi_ms * 1e-3) / 1e9
+        traffic = bounds = lds_rates = None
+        tf = os.path.join(ROOT, "profiles", "roi_fwd_traffic.json")
+        if os.path.exists(tf):
+            with open(tf) as fh:
+                rec = json.load(fh)
+            if rec.get("batch") == B and rec.get("channels") == C and args.config == "600x1000":
+                traffic = rec.get("hbm_bytes_per_launch")
+                bounds = rec.get("co_bounds")
+        lf = os.path.join(ROOT, "profiles", "lds_bank_conflicts.json")
+        if os.path.exists(lf):
+            with open(lf) as fh:
+                lds_rates = json.load(fh).get("rates")
         out = {
-            "metric": "images/sec (RPN anchor-match+proposal NMS+RoIPool) 600x1000",
+            "metric": "images/sec (RPN anchor-match+proposal NMS+RoIPool) "
+                      + ("600x1000" if args.config == "600x1000" else "768x768 ship"),
             "value": world * B * args.steps / elapsed,
             "unit": "images/s",
             "n_gpus": world,
@@ -247,19 +419,21 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "nms_us_per_image": nms_ms * 1e3 / B,
+            "nms_us_per_image_clustered": nms_cl_ms * 1e3 / B,
             "nms_us_per_image_in_step": nms_busy_ms * 1e3 / B,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "600x1000 image -> 37x62x9 = 20,646 anchors, G=42, top-12000 -> "
-                            "NMS 0.7 -> 2000, RoI crop 14 -> pool 7, C=512; "
+                "workload": wl["text"] + "; "
                             + ("inference stages only" if args.inference else
                                "with RPN + head target sampling (training forward)"),
                 "images_per_gpu_per_step": B,
+                "global_batch": B * world,
                 "batches_in_flight": args.depth,
                 "mean_kept_proposals": kept,
+                "clustered_nms_mean_kept": nms_cl_kept,
             },
             "verified": verified,
             "roofline": {
@@ -274,10 +448,16 @@ def main():
                 "avg_launch_ms_alone": roi_alone_ms,
                 "frac_alone": alg / (roi_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_launch": alg,
+                "co_bounds": bounds,
             },
         }
+        if kernels is not None:
+            out["kernels"] = kernels
+        if lds_rates is not None:
+            out["lds_bank_conflict_rate"] = lds_rates
         if not args.no_cpu_baseline and world == 1:       # the CPU leg is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(cfg, fmap, score, coord, gt, label)
+            out["cpu_baseline_numpy"] = cpu_baseline_numpy(cfg, fmap, score, coord, gt, label)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -55,3 +55,33 @@ def test_two_ranks_equal_one_rank(tmp_path):
     pc = O.proposal_creator(d["score"], d["coord"], O.make_anchor(8, 8), pre_k=200, post_n=40)
     np.testing.assert_array_equal(np.load(tmp_path / "counts.npy"), pc["counts"])
     np.testing.assert_array_equal(np.load(tmp_path / "keep.npy"), pc["keep_pos"])
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` from a bare shell (no launcher, WORLD_SIZE unset) must not
+    silently benchmark one rank: the script starts torch.distributed.run itself and rank 0
+    reports n_gpus = 2.  --rendezvous-only stops after the process group's first collective,
+    so the launch path is exercised without a GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend",
+                          "gloo", "--rendezvous-only"], env=env, capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["max_rank_plus_1"] == 2.0
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2",
+                          "--rendezvous-only"], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "WORLD_SIZE" in (out.stderr + out.stdout)
