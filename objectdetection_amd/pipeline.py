@@ -44,7 +44,8 @@ def _p(t):
 class RegionProposalPath:
     def __init__(self, cfg: PathConfig = REFERENCE, batch: int = 1, channels: int = 512,
                  device="cuda", train: bool = True, want_winner: bool = False,
-                 fuse_pool: bool = True, depth: int = 1, topk: str = "sort"):
+                 fuse_pool: bool = True, depth: int = 1, topk: str = "sort",
+                 alloc_pooled: bool = True):
         if depth not in (1, 2):
             raise ValueError("depth must be 1 or 2")
         if topk not in ("sort", "lds"):
@@ -63,8 +64,10 @@ class RegionProposalPath:
         self.pool = cfg.pool if fuse_pool else 1
         ph, pw = cfg.crop[0] // self.pool, cfg.crop[1] // self.pool
         K, R = cfg.pre_k, cfg.post_n
-        self.pooled = e((B, R, ph, pw, channels), f32)
-        self.winner = e((B, R, ph, pw, channels), u8) if want_winner else None
+        # alloc_pooled=False: every run() is called with skip_roi=True (the caller owns the
+        # pooled tensor), so the path holds no output buffer for the crop + pool stage
+        self.pooled = e((B, R, ph, pw, channels), f32) if alloc_pooled else None
+        self.winner = e((B, R, ph, pw, channels), u8) if want_winner and alloc_pooled else None
         self._sets = []
         for _ in range(depth):
             d = dict(top_scores=e((B, K), f32), top_idx=e((B, K), i32), cand=e((B, K, 4), f32),
@@ -139,15 +142,19 @@ class RegionProposalPath:
     def run(self, fmap: torch.Tensor, score: torch.Tensor, coord: torch.Tensor,
             gt: Optional[torch.Tensor] = None, label: Optional[torch.Tensor] = None,
             seed: int = 0, image_base: int = 0, roi_events=None, inputs_ready=None,
-            nms_events=None):
+            nms_events=None, skip_roi: bool = False):
         """fmap [B,H,W,C] channels-last, score [B,H,W,A], coord [B,H,W,4A],
         gt [B,G,4], label [B,G] i64 (both only when train).  Returns self.
 
         inputs_ready: an event after which the inputs may be read.  Without it the inputs are
         taken to be ready where the caller's stream stands at the call, which with depth=2
-        orders this batch's proposals behind everything already queued there (no overlap)."""
+        orders this batch's proposals behind everything already queued there (no overlap).
+        skip_roi: leave the crop + pool stage to the caller (a training step runs it as a
+        differentiable op on the proposals this call produced)."""
         cfg, B, N = self.cfg, self.B, self.cfg.N
         self._validate(fmap, score, coord, gt, label)
+        if self.pooled is None and not skip_roi:
+            raise ValueError("this path was built with alloc_pooled=False: call run(skip_roi=True)")
         d = self._sets[self._calls % self.depth]
         self._calls += 1
         self._bind(d)
@@ -216,9 +223,10 @@ class RegionProposalPath:
         sb, sh, sw, sc = fmap.stride()
         if roi_events is not None:
             roi_events[0].record(main)
-        check("frcnn_roi_crop_pool_fwd", lib.frcnn_roi_crop_pool_fwd(
-            _p(fmap), B, cfg.H, cfg.W, self.C, sb, sh, sw, sc, _p(d["proposed"]), cfg.post_n,
-            cfg.crop[0], cfg.crop[1], self.pool, _p(self.pooled), _p(self.winner), st))
+        if not skip_roi:
+            check("frcnn_roi_crop_pool_fwd", lib.frcnn_roi_crop_pool_fwd(
+                _p(fmap), B, cfg.H, cfg.W, self.C, sb, sh, sw, sc, _p(d["proposed"]), cfg.post_n,
+                cfg.crop[0], cfg.crop[1], self.pool, _p(self.pooled), _p(self.winner), st))
         if roi_events is not None:
             roi_events[1].record(main)
         if self.train:
