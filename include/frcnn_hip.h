@@ -191,13 +191,23 @@ int frcnn_roi_crop_pool_fwd(const float* fmap, int B, int H, int W, int C,
  * has at least n workgroups (B * C/32 * bands), the layout is channels-last with C % 32 == 0 and
  * crop <= 16 x 16; every other call is forwarded to frcnn_roi_crop_pool_fwd, so the entry
  * point accepts whatever that one accepts (on the 600x1000 workload the per-RoI kernel is the
- * faster one: 4.0 ms against 4.6 ms at B = 64). */
+ * faster one: 4.0 ms against 4.6 ms at B = 64).
+ * Planar feature maps ([B,C,H,W] contiguous, i.e. sw == 1, sh == W, sc == H*W, sb == C*H*W): when
+ * the workspace holds B*H*W*C*4 bytes beyond frcnn_roi_fwd_workspace_bytes(B,R), the map is
+ * transposed into it once (frcnn_nchw_to_nhwc) and the channels-last kernels run on the copy;
+ * with a smaller workspace the any-stride kernel runs on the original. */
 size_t frcnn_roi_fwd_workspace_bytes(int B, int R);
 int frcnn_roi_crop_pool_fwd_ws(const float* fmap, int B, int H, int W, int C,
                                int64_t sb, int64_t sh, int64_t sw, int64_t sc,
                                const float* rois, int R, int crop_h, int crop_w, int pool,
                                float* out, uint8_t* winner, void* workspace,
                                size_t workspace_bytes, frcnn_stream_t stream);
+
+/* [B,C,H,W] contiguous -> [B,H,W,C] contiguous (dst != src), tiled through LDS: the layout
+ * change in front of the channels-last RoI kernels for callers whose backbone emits planar
+ * maps (the reference's maps are channels-last already, module/model.py:12-17). */
+int frcnn_nchw_to_nhwc(const float* src, int B, int C, int H, int W, float* dst,
+                       frcnn_stream_t stream);
 
 /* ---- a13: adjoint of a7 + a8 ---------------------------------------------------------
  * The reference never differentiates the crop (stop_gradient,

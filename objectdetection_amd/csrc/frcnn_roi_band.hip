@@ -390,6 +390,28 @@ roi_fwd_band_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
     }
 }
 
+// ---- [B,C,H,W] contiguous -> [B,H,W,C] contiguous, 64 x 64 tiles through LDS: reads run along
+// H*W, writes along C, both 256 bytes per wave row.
+__global__ void __launch_bounds__(256)
+nchw_to_nhwc_kernel(const float* __restrict__ src, int C, int HW, float* __restrict__ dst) {
+    __shared__ float tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const float* s = src + (size_t)blockIdx.z * C * HW;
+    float* d = dst + (size_t)blockIdx.z * C * HW;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = c0 + ty + 4 * i, pp = p0 + tx;
+        if (c < C && pp < HW) tile[ty + 4 * i][tx] = s[(size_t)c * HW + pp];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int pp = p0 + ty + 4 * i, c = c0 + tx;
+        if (c < C && pp < HW) d[(size_t)pp * C + c] = tile[tx][ty + 4 * i];
+    }
+}
+
 // rows of the bands for an H x W map and crop height ch: every output row of a box inside the
 // image spans at most V + 1 feature rows, bands are T rows every S = T - V rows.
 struct BandPlan { int nb, S, T; bool ok; };
@@ -421,6 +443,16 @@ extern "C" size_t frcnn_roi_fwd_workspace_bytes(int B, int R) {
     return roi_ws_align((size_t)B * R * sizeof(RoiDesc));
 }
 
+extern "C" int frcnn_nchw_to_nhwc(const float* src, int B, int C, int H, int W, float* dst,
+                                  frcnn_stream_t stream) {
+    if (!src || !dst || src == dst || B <= 0 || C <= 0 || H <= 0 || W <= 0) return FRCNN_E_BADARG;
+    const long long HW = (long long)H * W;
+    if (HW > 0x7FFFFFFFll || B > 65535 || (C + 63) / 64 > 65535) return FRCNN_E_UNSUPPORTED;
+    FRCNN_LAUNCH(nchw_to_nhwc_kernel, dim3((unsigned)((HW + 63) / 64), (unsigned)((C + 63) / 64), B),
+                 dim3(256), 0, (hipStream_t)stream, src, C, (int)HW, dst);
+    return FRCNN_OK;
+}
+
 extern "C" int frcnn_roi_crop_pool_fwd_ws(const float* fmap, int B, int H, int W, int C, int64_t sb,
                                           int64_t sh, int64_t sw, int64_t sc, const float* rois,
                                           int R, int crop_h, int crop_w, int pool, float* out,
@@ -431,6 +463,22 @@ extern "C" int frcnn_roi_crop_pool_fwd_ws(const float* fmap, int B, int H, int W
         return FRCNN_E_BADARG;
     if (pool != 1 && pool != 2) return FRCNN_E_BADARG;
     if (crop_h % pool || crop_w % pool) return FRCNN_E_BADARG;
+    // a feature map stored [B,C,H,W] (planar): with room for a channels-last copy behind the
+    // descriptors, transpose it once (two passes over 4*H*W*C bytes per image) and run the
+    // channels-last kernels on the copy instead of the any-stride kernel on the original
+    if (sw == 1 && sh == W && sc == (int64_t)H * W && sb == (int64_t)C * H * W && C > 1 &&
+        (C % 4) == 0 && workspace && (reinterpret_cast<uintptr_t>(workspace) % 16) == 0) {
+        const size_t desc_bytes = frcnn_roi_fwd_workspace_bytes(B, R);
+        const size_t copy_bytes = (size_t)B * H * W * C * sizeof(float);
+        if (workspace_bytes >= desc_bytes + copy_bytes) {
+            float* copy = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + desc_bytes);
+            const int rc = frcnn_nchw_to_nhwc(fmap, B, C, H, W, copy, stream);
+            if (rc != FRCNN_OK) return rc;
+            return frcnn_roi_crop_pool_fwd_ws(copy, B, H, W, C, (int64_t)H * W * C, (int64_t)W * C, C,
+                                              1, rois, R, crop_h, crop_w, pool, out, winner,
+                                              workspace, desc_bytes, stream);
+        }
+    }
     const bool aligned = sc == 1 && (C % BD_CG) == 0 && (sb % 4) == 0 && (sh % 4) == 0 &&
                          (sw % 4) == 0 && sb >= 0 && sh >= 0 && sw >= 0 &&
                          (reinterpret_cast<uintptr_t>(fmap) % 16) == 0 &&

@@ -215,8 +215,24 @@ def nms(boxes: torch.Tensor, iou_threshold: float, post_n: int,
     return proposed, keep, count
 
 
-def roi_fwd_workspace_bytes(B: int, R: int) -> int:
-    return int(lib.frcnn_roi_fwd_workspace_bytes(B, R))
+def roi_fwd_workspace_bytes(B: int, R: int, planar_shape: Optional[Tuple[int, int, int]] = None) -> int:
+    """Workspace of frcnn_roi_crop_pool_fwd_ws; planar_shape = (H, W, C) adds the room for the
+    channels-last copy of a [B,C,H,W] feature map."""
+    n = int(lib.frcnn_roi_fwd_workspace_bytes(B, R))
+    if planar_shape is not None:
+        H, W, Cc = planar_shape
+        n += B * H * W * Cc * 4
+    return n
+
+
+def nchw_to_nhwc(x: torch.Tensor) -> torch.Tensor:
+    """[B,C,H,W] contiguous -> new [B,H,W,C] contiguous tensor (frcnn_nchw_to_nhwc)."""
+    s = _cont(x, "x", torch.float32)
+    B, Cc, H, W = s.shape
+    out = torch.empty((B, H, W, Cc), dtype=torch.float32, device=s.device)
+    with torch.cuda.device(s.device):
+        check("frcnn_nchw_to_nhwc", lib.frcnn_nchw_to_nhwc(_ptr(s), B, Cc, H, W, _ptr(out), _stream(s)))
+    return out
 
 
 def roi_crop_pool_fwd(fmap: torch.Tensor, rois: torch.Tensor, crop: Tuple[int, int] = (14, 14),

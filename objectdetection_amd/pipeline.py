@@ -45,7 +45,7 @@ class RegionProposalPath:
     def __init__(self, cfg: PathConfig = REFERENCE, batch: int = 1, channels: int = 512,
                  device="cuda", train: bool = True, want_winner: bool = False,
                  fuse_pool: bool = True, depth: int = 1, topk: str = "sort",
-                 alloc_pooled: bool = True):
+                 alloc_pooled: bool = True, fmap_planar: bool = False):
         if depth not in (1, 2):
             raise ValueError("depth must be 1 or 2")
         if topk not in ("sort", "lds"):
@@ -66,6 +66,11 @@ class RegionProposalPath:
         K, R = cfg.pre_k, cfg.post_n
         # alloc_pooled=False: every run() is called with skip_roi=True (the caller owns the
         # pooled tensor), so the path holds no output buffer for the crop + pool stage
+        # workspace of frcnn_roi_crop_pool_fwd_ws; fmap_planar: the caller's feature maps are
+        # stored [B,C,H,W] (passed as the permuted [B,H,W,C] view) and are transposed into this
+        # workspace before the channels-last RoI kernel runs
+        self.roi_ws = e((ops.roi_fwd_workspace_bytes(
+            B, R, (cfg.H, cfg.W, channels) if fmap_planar else None),), u8)
         self.pooled = e((B, R, ph, pw, channels), f32) if alloc_pooled else None
         self.winner = e((B, R, ph, pw, channels), u8) if want_winner and alloc_pooled else None
         self._sets = []
@@ -224,9 +229,10 @@ class RegionProposalPath:
         if roi_events is not None:
             roi_events[0].record(main)
         if not skip_roi:
-            check("frcnn_roi_crop_pool_fwd", lib.frcnn_roi_crop_pool_fwd(
+            check("frcnn_roi_crop_pool_fwd_ws", lib.frcnn_roi_crop_pool_fwd_ws(
                 _p(fmap), B, cfg.H, cfg.W, self.C, sb, sh, sw, sc, _p(d["proposed"]), cfg.post_n,
-                cfg.crop[0], cfg.crop[1], self.pool, _p(self.pooled), _p(self.winner), st))
+                cfg.crop[0], cfg.crop[1], self.pool, _p(self.pooled), _p(self.winner),
+                _p(self.roi_ws), self.roi_ws.numel(), st))
         if roi_events is not None:
             roi_events[1].record(main)
         if self.train:

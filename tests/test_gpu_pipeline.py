@@ -113,3 +113,26 @@ def test_inputs_ready_from_another_stream_depth1(dev):
     torch.cuda.synchronize()
     for k, v in want.items():
         assert torch.equal(v, getattr(path, k)), k
+
+
+def test_planar_feature_map_gives_the_same_path(dev):
+    """A backbone that emits [B,C,H,W] maps: the path transposes them into its workspace and
+    gives the channels-last run's results bit for bit."""
+    from objectdetection_amd.config import PathConfig
+    from objectdetection_amd.pipeline import RegionProposalPath
+    g = np.load(os.path.join(GOLD, "ref_small.npz"), allow_pickle=False)
+    cfg = PathConfig(H=int(g["H"]), W=int(g["W"]), scales=tuple(g["scales"].tolist()),
+                     G=int(g["G"]), pre_k=int(g["pre_k"]), post_n=int(g["post_n"]))
+    B, C = g["gt"].shape[0], 64
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(6)
+    fmap = torch.rand((B, cfg.H, cfg.W, C), generator=gen, device=dev)
+    score = torch.rand((B, cfg.H, cfg.W, cfg.A), generator=gen, device=dev)
+    coord = torch.randn((B, cfg.H, cfg.W, 4 * cfg.A), generator=gen, device=dev) * 0.5
+    a = RegionProposalPath(cfg, B, C, dev, train=False, want_winner=True)
+    a.run(fmap, score, coord)
+    planar = fmap.permute(0, 3, 1, 2).contiguous().permute(0, 2, 3, 1)
+    b = RegionProposalPath(cfg, B, C, dev, train=False, want_winner=True, fmap_planar=True)
+    b.run(planar, score, coord)
+    torch.cuda.synchronize()
+    assert torch.equal(a.pooled, b.pooled) and torch.equal(a.winner, b.winner)

@@ -42,16 +42,34 @@ def _boxes(rng, n, H, W):
     return np.array(out, np.float32)
 
 
-@pytest.fixture(params=["per_roi", "band"])
+class _Path:
+    """One way through the forward entry points: how the feature map is laid out and which
+    workspace goes with the call."""
+
+    def __init__(self, kind):
+        self.kind = kind
+
+    def fmap(self, t):
+        if self.kind != "planar":
+            return t
+        return t.permute(0, 3, 1, 2).contiguous().permute(0, 2, 3, 1)     # [B,C,H,W] storage
+
+    def ws(self, B, R, H, W, C, dev):
+        from objectdetection_amd import ops
+        if self.kind == "per_roi":
+            return None
+        n = ops.roi_fwd_workspace_bytes(B, R, (H, W, C) if self.kind == "planar" else None)
+        return torch.empty(n, dtype=torch.uint8, device=dev)
+
+
+@pytest.fixture(params=["per_roi", "band", "planar"])
 def ws_for(request, monkeypatch):
-    """Both forward entry points: frcnn_roi_crop_pool_fwd (one wave per RoI and slice) and
-    frcnn_roi_crop_pool_fwd_ws with its band kernel forced on at test sizes."""
-    from objectdetection_amd import ops
-    if request.param == "per_roi":
-        return lambda B, R, dev: None
-    monkeypatch.setenv("FRCNN_ROI_BAND_MIN_WG", "1")
-    return lambda B, R, dev: torch.empty(ops.roi_fwd_workspace_bytes(B, R), dtype=torch.uint8,
-                                         device=dev)
+    """The forward entry points: frcnn_roi_crop_pool_fwd (one wave per RoI and slice),
+    frcnn_roi_crop_pool_fwd_ws with its band kernel forced on at test sizes, and the same entry
+    point on a planar [B,C,H,W] map (transposed into the workspace, then the per-RoI kernel)."""
+    if request.param == "band":
+        monkeypatch.setenv("FRCNN_ROI_BAND_MIN_WG", "1")
+    return _Path(request.param)
 
 
 @pytest.mark.parametrize("C,H,W", [(64, 31, 31), (128, 37, 62), (192, 20, 45), (512, 37, 62),
@@ -67,8 +85,9 @@ def test_roi_forward_stress(dev, ws_for, C, H, W):
     rois[0, 1] = [np.nan, 0.1, 0.5, 0.6]
     rois[0, 2] = [0.2, 0.2, 0.2, 0.2]
     for pool, win in ((2, True), (2, False), (1, False)):
-        out, w = ops.roi_crop_pool_fwd(torch.tensor(fm, device=dev), torch.tensor(rois, device=dev),
-                                       (14, 14), pool, want_winner=win, workspace=ws_for(B, R, dev))
+        out, w = ops.roi_crop_pool_fwd(ws_for.fmap(torch.tensor(fm, device=dev)),
+                                       torch.tensor(rois, device=dev), (14, 14), pool,
+                                       want_winner=win, workspace=ws_for.ws(B, R, H, W, C, dev))
         for b in range(B):
             ro, rw = c_oracle.roi_crop_pool(lib, fm[b], rois[b], (14, 14), pool, want_winner=win)
             got = out[b].cpu().numpy()
@@ -88,8 +107,17 @@ def test_roi_forward_other_crop_sizes(dev, ws_for):
     fm = rng.standard_normal((1, H, W, C)).astype(np.float32)
     rois = _boxes(rng, 300, H, W)[None]
     for crop, pool in (((16, 16), 2), ((12, 12), 1), ((7, 7), 1), ((14, 8), 2)):
-        out, _ = ops.roi_crop_pool_fwd(torch.tensor(fm, device=dev), torch.tensor(rois, device=dev),
-                                       crop, pool, workspace=ws_for(1, 300, dev))
+        out, _ = ops.roi_crop_pool_fwd(ws_for.fmap(torch.tensor(fm, device=dev)),
+                                       torch.tensor(rois, device=dev), crop, pool,
+                                       workspace=ws_for.ws(1, 300, H, W, C, dev))
         ro, _ = c_oracle.roi_crop_pool(lib, fm[0], rois[0], crop, pool, want_winner=False)
         got = out[0].cpu().numpy()
         assert ((got == ro) | (np.isnan(got) & np.isnan(ro))).all(), (crop, pool)
+
+
+def test_nchw_to_nhwc(dev):
+    from objectdetection_amd import ops
+    rng = np.random.default_rng(8)
+    for shape in ((2, 512, 37, 62), (1, 5, 3, 7), (3, 64, 1, 1), (1, 130, 9, 70)):
+        x = torch.tensor(rng.standard_normal(shape).astype(np.float32), device=dev)
+        assert torch.equal(ops.nchw_to_nhwc(x), x.permute(0, 2, 3, 1).contiguous())
