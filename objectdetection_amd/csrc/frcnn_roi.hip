@@ -164,17 +164,42 @@ __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rs, uint32_t 
     const f32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
     return make_float4(v.x, v.y, v.z, v.w);
 }
-// 16-byte buffer store with a scalar row offset.  The store keeps reading its data registers
-// for a few cycles after issue and hipcc (ROCm 7.2) schedules no wait state before a following
-// instruction that overwrites them when the offset is a scalar register: observed on gfx950 as
-// the y component of lanes 12-15 of each 16-lane row taking the NEXT value.  The s_nop keeps
-// the registers stable; the store is issued from asm so that nothing can be placed in between.
+// 16-byte buffer store with a scalar row offset.  gfx9-family hardware needs a wait state
+// between a vector-memory store of more than 64 bits and a vector instruction that overwrites
+// the store's data registers.  hipcc (ROCm 7.2) inserts it only when the store's soffset is NOT
+// a register (GCNHazardRecognizer::createsVALUHazard exempts the register form), but gfx950
+// needs it with a scalar-register offset as well: the compiler-scheduled store below
+// (FRCNN_STORE_VARIANT 1) is followed directly by `v_pk_mul_f32 v[10:11], ...` on its own data
+// registers v[10:13], and the x / y components of some lanes reach memory with the NEXT row's
+// values.  Measured with the stress test per variant: compiler store + scalar offset FAILS,
+// compiler store with the offset added into the VGPR (the compiler then pads) passes, asm
+// store without a wait state FAILS, with one (s_nop 0) or two (s_nop 1) wait states passes.
+// The store is issued from asm together with two wait states (what the compiler uses for the
+// non-register form on gfx940 and later), so nothing can be scheduled in between.
+#ifndef FRCNN_STORE_VARIANT
+#define FRCNN_STORE_VARIANT 0    // experiments on the store hazard: 1..5, see buf_store4
+#endif
 __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff,
                                            float4 v) {
     f32x4 t;
     t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
-    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 3"
+#if FRCNN_STORE_VARIANT == 1        // compiler-scheduled store, scalar row offset
+    __builtin_amdgcn_raw_buffer_store_b128(t, rs, voff, soff, 0);
+#elif FRCNN_STORE_VARIANT == 2      // compiler-scheduled store, row offset added into the VGPR
+    __builtin_amdgcn_raw_buffer_store_b128(t, rs, voff + soff, 0, 0);
+#elif FRCNN_STORE_VARIANT == 3      // asm store, no wait state behind it
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen"
                  :: "v"(t), "v"(voff), "s"(rs), "s"(soff) : "memory");
+#elif FRCNN_STORE_VARIANT == 4      // one wait state
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 0"
+                 :: "v"(t), "v"(voff), "s"(rs), "s"(soff) : "memory");
+#elif FRCNN_STORE_VARIANT == 5      // two wait states
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1"
+                 :: "v"(t), "v"(voff), "s"(rs), "s"(soff) : "memory");
+#else
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1"
+                 :: "v"(t), "v"(voff), "s"(rs), "s"(soff) : "memory");
+#endif
 }
 template <bool B> struct BoolTag { static constexpr bool value = B; };
 template <int I> struct IntTag { static constexpr int value = I; };

@@ -116,15 +116,6 @@ __device__ __forceinline__ Quad q_lerp(Quad p, Quad q, float w) {
     r.b = p.b + pk_sub(q.b, p.b) * w2;
     return r;
 }
-// dst = p + (q - p) * w, the last instruction writing dst's own registers: a row set that one
-// path of the walk rewrites and another leaves alone then stays in one place (the register
-// allocator otherwise copies both sets in and out of every sample row's code)
-__device__ __forceinline__ void q_lerp_into(Quad& dst, Quad p, Quad q, float w) {
-    const f32x2 w2 = {w, w};
-    const f32x2 ta = pk_sub(q.a, p.a) * w2, tb = pk_sub(q.b, p.b) * w2;
-    asm("v_pk_add_f32 %0, %1, %2" : "+v"(dst.a) : "v"(p.a), "v"(ta));
-    asm("v_pk_add_f32 %0, %1, %2" : "+v"(dst.b) : "v"(p.b), "v"(tb));
-}
 __device__ __forceinline__ Quad q_from(f32x4 t) {
     Quad r;
     r.a = __builtin_shufflevector(t, t, 0, 1);

@@ -121,3 +121,28 @@ def test_nchw_to_nhwc(dev):
     for shape in ((2, 512, 37, 62), (1, 5, 3, 7), (3, 64, 1, 1), (1, 130, 9, 70)):
         x = torch.tensor(rng.standard_normal(shape).astype(np.float32), device=dev)
         assert torch.equal(ops.nchw_to_nhwc(x), x.permute(0, 2, 3, 1).contiguous())
+
+
+def test_store_data_survives_the_next_row(dev):
+    """Guard for the 16-byte store with a scalar row offset (a vector instruction of the next
+    row must not overwrite the store's data registers while the store still reads them: seen as
+    the x / y components of channel quads 12-15 of a 16-lane group carrying the NEXT pooled
+    row's values).  Every feature row holds its own value range and the boxes sit on grid
+    lines, so a value from another row is off by thousands, not by rounding."""
+    from objectdetection_amd import ops
+    lib = c_oracle.load()
+    H, W, C = 29, 29, 128
+    y = np.arange(H, dtype=np.float32)[:, None, None] * 1000.0
+    x = np.arange(W, dtype=np.float32)[None, :, None] * 10.0
+    c = np.arange(C, dtype=np.float32)[None, None, :] / 256.0
+    fm = (y + x + c)[None].astype(np.float32)
+    rois = np.array([[[0, 0, 1, 1], [0, 0, 13 / 28, 13 / 28], [7 / 28, 7 / 28, 1, 1],
+                      [0.1, 0.2, 0.9, 0.7]]], np.float32)
+    rois = np.tile(rois, (1, 50, 1))
+    out, _ = ops.roi_crop_pool_fwd(torch.tensor(fm, device=dev), torch.tensor(rois, device=dev))
+    ro, _ = c_oracle.roi_crop_pool(lib, fm[0], rois[0], (14, 14), 2, want_winner=False)
+    got = out[0].cpu().numpy()
+    bad = np.argwhere(got != ro)
+    assert len(bad) == 0, ("first mismatches (roi, p, q, channel):", bad[:6],
+                           "channel quads", sorted(set((bad[:, 3] // 4 % 16).tolist())),
+                           "components", sorted(set((bad[:, 3] % 4).tolist())))
