@@ -6,6 +6,7 @@
 // followed by the pool x pool, stride pool maximum (first maximum wins).
 // gfx950, wave64.  -ffp-contract=off.
 #include "frcnn_common.h"
+#include <cstdlib>
 
 namespace frcnn {
 
@@ -288,6 +289,17 @@ __device__ __forceinline__ void wait_vm_at_most(int n) {
         else if (n == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
         else             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     }
+}
+
+// The same wait with two outcomes instead of nine: nothing issued since the staged row ->
+// vmcnt(0); anything -> vmcnt(k), k (compile time, <= 8) = the stores of ONE finished output
+// row, the fewest a non-zero count can be.  Under-counting only waits for a few stores more;
+// the nine-way branch tree cost some twenty scalar instructions per feature row.
+template <int K>
+__device__ __forceinline__ void wait_vm_zero_or(int n) {
+    static_assert(K >= 1 && K <= 8, "vmcnt immediate");
+    if (n == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(K) : "memory");
 }
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
@@ -665,7 +677,7 @@ __device__ __forceinline__ void staged_walk_hot(const StageCtx& c, const RowDup&
     };
     auto step = [&](int j, auto slot_c, Quad (&hc)[NS], const Quad (&hp)[NS]) {
         constexpr int slot = decltype(slot_c)::value;
-        wait_vm_at_most(issued - mark[slot]);              // row j has landed in its slot
+        wait_vm_zero_or<NQ * (WIN ? 2 : 1)>(issued - mark[slot]);   // row j has landed in its slot
         const unsigned char* sp = c.ring + slot * ST_SLOT_BYTES;
         Quad cl[NS], cr[NS];
 #pragma unroll
@@ -1100,8 +1112,8 @@ __device__ __forceinline__ void bwd_apply_candidate(
 template <int POOL, int NQ, int LW>
 __global__ void __launch_bounds__(64)
 roi_bwd_wave_kernel(const float* __restrict__ dY, const uint8_t* __restrict__ winner,
-                    const float4* __restrict__ rois, int R, int H, int W, int C, int ch, int cw,
-                    float* __restrict__ dfmap) {
+                    const float4* __restrict__ rois, int R, int r_begin, int r_end, int H, int W,
+                    int C, int ch, int cw, float* __restrict__ dfmap) {
     // The sample geometry of a candidate takes LW lanes per axis (crop <= LW), so one
     // evaluation serves NC = 32 / LW candidates: lanes [2*LW*t, 2*LW*t + LW) hold the sample
     // rows of candidate t, the next LW lanes its sample columns.
@@ -1118,9 +1130,18 @@ roi_bwd_wave_kernel(const float* __restrict__ dY, const uint8_t* __restrict__ wi
     const int cq = (int)blockIdx.y * 64 * NQ + lane;         // blockIdx.y = slice of 256*NQ channels
     const int ph = ch / POOL, pw = cw / POOL;
     const int C4 = C >> 2;
+    // RoIs [r_begin, r_end) of every image: a launch per range keeps the cells of a band within
+    // a few dozen RoIs of each other, so the pooled gradients they share are still in the L2
+    // when the next cell asks for them.  Later ranges continue the sums of the earlier ones
+    // (same order of additions as one pass over all RoIs).
+    float* dst = dfmap + (((size_t)b * H + y) * W + x) * C;
     float4 acc[NQ];
 #pragma unroll
-    for (int u = 0; u < NQ; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int u = 0; u < NQ; ++u) {
+        const int c4 = cq + 64 * u;
+        acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r_begin > 0 && c4 < C4) acc[u] = *reinterpret_cast<const float4*>(dst + c4 * 4);
+    }
     const float4* rb = rois + (size_t)b * R;
     const int field = lane / LW;
     const int ci = field >> 1;                               // this lane's candidate of the group
@@ -1129,11 +1150,11 @@ roi_bwd_wave_kernel(const float* __restrict__ dY, const uint8_t* __restrict__ wi
     const int target = isx ? x : y;
     const int ns = isx ? cw : ch, dim = isx ? W : H;
 #pragma unroll 1
-    for (int r0 = 0; r0 < R; r0 += 64) {
+    for (int r0 = r_begin; r0 < r_end; r0 += 64) {
         const int r = r0 + lane;
         float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
         bool cand = false;
-        if (r < R) {
+        if (r < r_end) {
             box = rb[r];
             cand = axis_reaches(box.x, box.z, H, ch, y) && axis_reaches(box.y, box.w, W, cw, x);
         }
@@ -1178,7 +1199,6 @@ roi_bwd_wave_kernel(const float* __restrict__ dY, const uint8_t* __restrict__ wi
             }
         }
     }
-    float* dst = dfmap + (((size_t)b * H + y) * W + x) * C;
 #pragma unroll
     for (int u = 0; u < NQ; ++u) {
         const int c4 = cq + 64 * u;
@@ -1278,14 +1298,21 @@ extern "C" int frcnn_roi_crop_pool_bwd(const float* dY, const uint8_t* winner, c
         const int nsl = (C / 4 + 64 * nqk - 1) / (64 * nqk);
         const bool pack2 = crop_h <= 16 && crop_w <= 16;      // two candidates per evaluation
         const dim3 cgrid((unsigned)(((long long)H * W + 7) / 8 * 8), (unsigned)nsl, (unsigned)B);
+        int chunk = 512;                 // RoIs per launch (a multiple of 64): 241-245 us per image at 256-512, 281 in one launch (B = 64)
+        if (const char* e = getenv("FRCNN_BWD_CHUNK")) chunk = atoi(e);
+        if (chunk <= 0 || chunk > R) chunk = R;
+        chunk = (chunk + 63) / 64 * 64;
 #define FRCNN_BWD(P, Q)                                                                          \
     do {                                                                                         \
-        if (pack2)                                                                               \
-            FRCNN_LAUNCH((roi_bwd_wave_kernel<P, Q, 16>), cgrid, dim3(64), 0, st, dY, winner, rb, \
-                         R, H, W, C, crop_h, crop_w, dfmap);                                     \
-        else                                                                                     \
-            FRCNN_LAUNCH((roi_bwd_wave_kernel<P, Q, 32>), cgrid, dim3(64), 0, st, dY, winner, rb, \
-                         R, H, W, C, crop_h, crop_w, dfmap);                                     \
+        for (int rb0 = 0; rb0 < R; rb0 += chunk) {                                               \
+            const int re = rb0 + chunk < R ? rb0 + chunk : R;                                    \
+            if (pack2)                                                                           \
+                FRCNN_LAUNCH((roi_bwd_wave_kernel<P, Q, 16>), cgrid, dim3(64), 0, st, dY, winner, \
+                             rb, R, rb0, re, H, W, C, crop_h, crop_w, dfmap);                    \
+            else                                                                                 \
+                FRCNN_LAUNCH((roi_bwd_wave_kernel<P, Q, 32>), cgrid, dim3(64), 0, st, dY, winner, \
+                             rb, R, rb0, re, H, W, C, crop_h, crop_w, dfmap);                    \
+        }                                                                                        \
     } while (0)
 #define FRCNN_BWD_P(P)                                                                           \
     do {                                                                                         \
