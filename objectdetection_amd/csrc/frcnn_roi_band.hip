@@ -148,6 +148,65 @@ __device__ __forceinline__ uint32_t band_match(uint4 w, uint32_t want) {
     return m;
 }
 
+// One sample row of the walk, written in assembly: the conditional refills of the two row sets
+// are branches inside one statement whose set operands are tied ("+v"), so the compiler sees
+// straight-line code and cannot answer the conditional writes with register copies (it did:
+// about twenty v_mov_b64 per sample row in every C++ formulation of this step).
+// v[112:127] are the staging registers of the four 16-byte LDS reads of a feature row.
+// Dependent packed instructions are kept one instruction apart (gfx940-family forwarding
+// hazard of instructions that write through op_sel / packed destinations).
+#define BD_LOADROW(OFF, S)                                                                   \
+    "v_add_u32 v112, " OFF ", %[a0]\n"                                                       \
+    "v_add_u32 v116, " OFF ", %[a1]\n"                                                       \
+    "v_add_u32 v120, " OFF ", %[a2]\n"                                                       \
+    "v_add_u32 v124, " OFF ", %[a3]\n"                                                       \
+    "ds_read_b128 v[112:115], v112\n"                                                        \
+    "ds_read_b128 v[116:119], v116\n"                                                        \
+    "ds_read_b128 v[120:123], v120\n"                                                        \
+    "ds_read_b128 v[124:127], v124\n"                                                        \
+    "s_waitcnt lgkmcnt(2)\n"                                                                 \
+    "v_pk_add_f32 v[116:117], v[116:117], v[112:113] neg_lo:[0,1] neg_hi:[0,1]\n"            \
+    "v_pk_add_f32 v[118:119], v[118:119], v[114:115] neg_lo:[0,1] neg_hi:[0,1]\n"            \
+    "v_pk_mul_f32 v[116:117], %[fx0], v[116:117]\n"                                          \
+    "v_pk_mul_f32 v[118:119], %[fx0], v[118:119]\n"                                          \
+    "v_pk_add_f32 %[" S "0], v[112:113], v[116:117]\n"                                          \
+    "v_pk_add_f32 %[" S "1], v[114:115], v[118:119]\n"                                          \
+    "s_waitcnt lgkmcnt(0)\n"                                                                 \
+    "v_pk_add_f32 v[124:125], v[124:125], v[120:121] neg_lo:[0,1] neg_hi:[0,1]\n"            \
+    "v_pk_add_f32 v[126:127], v[126:127], v[122:123] neg_lo:[0,1] neg_hi:[0,1]\n"            \
+    "v_pk_mul_f32 v[124:125], %[fx1], v[124:125]\n"                                          \
+    "v_pk_mul_f32 v[126:127], %[fx1], v[126:127]\n"                                          \
+    "v_pk_add_f32 %[" S "2], v[120:121], v[124:125]\n"                                          \
+    "v_pk_add_f32 %[" S "3], v[122:123], v[126:127]\n"
+// v = L + (H - L) * fy for the four pairs
+#define BD_YLERP(L, H)                                                                       \
+    "v_pk_add_f32 %[v0a], %[" H "0], %[" L "0] neg_lo:[0,1] neg_hi:[0,1]\n"                        \
+    "v_pk_add_f32 %[v0b], %[" H "1], %[" L "1] neg_lo:[0,1] neg_hi:[0,1]\n"                        \
+    "v_pk_add_f32 %[v1a], %[" H "2], %[" L "2] neg_lo:[0,1] neg_hi:[0,1]\n"                        \
+    "v_pk_add_f32 %[v1b], %[" H "3], %[" L "3] neg_lo:[0,1] neg_hi:[0,1]\n"                        \
+    "v_pk_mul_f32 %[v0a], %[fy], %[v0a] op_sel_hi:[0,1]\n"                                   \
+    "v_pk_mul_f32 %[v0b], %[fy], %[v0b] op_sel_hi:[0,1]\n"                                   \
+    "v_pk_mul_f32 %[v1a], %[fy], %[v1a] op_sel_hi:[0,1]\n"                                   \
+    "v_pk_mul_f32 %[v1b], %[fy], %[v1b] op_sel_hi:[0,1]\n"                                   \
+    "v_pk_add_f32 %[v0a], %[" L "0], %[v0a]\n"                                                  \
+    "v_pk_add_f32 %[v0b], %[" L "1], %[v0b]\n"                                                  \
+    "v_pk_add_f32 %[v1a], %[" L "2], %[v1a]\n"                                                  \
+    "v_pk_add_f32 %[v1b], %[" L "3], %[v1b]\n"
+// bit 27 of the row word: both rows are new; bit 26: the ceil row is new; bit 25: the ceil row
+// lives in set A; bit 24 clear: the sample row lies outside the image (zeros)
+#define BD_ROWSTEP_HALF(TAG, SETLO, SETHI)                                                   \
+    "s_bitcmp1_b32 %[yw], 27\n"                                                              \
+    "s_cbranch_scc0 .Lbd_one" TAG "_%=\n"                                                    \
+    BD_LOADROW("%[lo]", SETLO)                                                              \
+    "s_branch .Lbd_hi" TAG "_%=\n"                                                           \
+    ".Lbd_one" TAG "_%=:\n"                                                                  \
+    "s_bitcmp1_b32 %[yw], 26\n"                                                              \
+    "s_cbranch_scc0 .Lbd_lerp" TAG "_%=\n"                                                   \
+    ".Lbd_hi" TAG "_%=:\n"                                                                   \
+    BD_LOADROW("%[hi]", SETHI)                                                              \
+    ".Lbd_lerp" TAG "_%=:\n"                                                                 \
+    BD_YLERP(SETLO, SETHI)
+
 // The lerped feature rows a wave holds: two register sets, feature row r lives in set r & 1.
 // A sample row's floor and ceil rows are neighbours, so they never compete for a set, and a
 // row that the next sample row needs again (as its floor row) is already where it belongs:
@@ -184,6 +243,8 @@ roi_fwd_band_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
     const RoiDesc* dimg = desc + (size_t)b * R;
     const size_t bin_stride = (size_t)C;                         // floats between output columns
     const uint32_t lds_adj = (uint32_t)quad * 16u - (uint32_t)r0 * rowpitch;
+    // byte address of the band inside the LDS (what a ds_read takes)
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)band_lds;
     // this wave's descriptor ring (private: no barrier, LDS operations of a wave stay in order)
     unsigned char* ring = band_lds + (size_t)T * rowpitch + (size_t)wave * BD_RING * BD_ENTRY;
     unsigned char* hdr = band_lds + (size_t)T * rowpitch + (size_t)BD_WAVES * BD_RING * BD_ENTRY +
@@ -269,14 +330,13 @@ roi_fwd_band_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
             uchar4 arg = make_uchar4(0, 0, 0, 0);
 
             // one sample row's two samples folded into the running maximum / stored
-            auto fold = [&](int sy, Quad v0, Quad v1) {
+            auto fold = [&](int oy, int ky, Quad v0, Quad v1) {
                 if (POOL == 1) {
-                    float* o = oroi + ((size_t)sy * PW + 2 * q) * bin_stride;
+                    float* o = oroi + ((size_t)oy * PW + 2 * q) * bin_stride;
                     if (live0) *reinterpret_cast<f32x4*>(o) = q_pack(v0);
                     if (live1) *reinterpret_cast<f32x4*>(o + bin_stride) = q_pack(v1);
                     return;
                 }
-                const int ky = sy % POOL;
                 if (WIN) {
                     const Quad vs[2] = {v0, v1};
 #pragma unroll
@@ -300,52 +360,59 @@ roi_fwd_band_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
                     best.b.x = vmax3(best.b.x, v0.b.x, v1.b.x); best.b.y = vmax3(best.b.y, v0.b.y, v1.b.y);
                 }
                 if (ky == POOL - 1 && q < PW) {
-                    const size_t o = ((size_t)(sy / POOL) * PW + q) * bin_stride;
+                    const size_t o = ((size_t)oy * PW + q) * bin_stride;
                     *reinterpret_cast<f32x4*>(oroi + o) = q_pack(best);
                     if (WIN) *reinterpret_cast<uchar4*>(wroi + o) = arg;
                 }
             };
-            auto lds_row = [&](uint32_t row, RowSet& st) {
-                const uint32_t roff = row * rowpitch;                               // uniform
-                const f32x4 c0 = *reinterpret_cast<const f32x4*>(band_lds + (a0 + roff));
-                const f32x4 c1 = *reinterpret_cast<const f32x4*>(band_lds + (a1 + roff));
-                const f32x4 c2 = *reinterpret_cast<const f32x4*>(band_lds + (a2 + roff));
-                const f32x4 c3 = *reinterpret_cast<const f32x4*>(band_lds + (a3 + roff));
-                st.h0 = q_lerp(q_from(c0), q_from(c1), fx0);
-                st.h1 = q_lerp(q_from(c2), q_from(c3), fx1);
-            };
+            const f32x2 fx0p = {fx0, fx0}, fx1p = {fx1, fx1};
+            const uint32_t la0 = a0 + lds_base, la1 = a1 + lds_base, la2 = a2 + lds_base,
+                           la3 = a3 + lds_base;
             bool have = false;                   // the sets hold the previous sample row's rows
-            bool in_band = false;
+#pragma unroll 1
+            for (int oy = 0; oy < PH; ++oy) {
+                if (!((rows >> oy) & 1u)) {                                         // uniform
+                    have = false;
+                    continue;
+                }
 #pragma unroll
-            for (int sy = 0; sy < BD_MAXCROP; ++sy) {
-                if (sy < ch) {                                                      // uniform
-                    if (sy % POOL == 0) in_band = (rows >> (sy / POOL)) & 1u;
-                    if (!in_band) {
-                        have = false;
-                    } else {
-                        const uint32_t yw = bd_rl(ydv, 2 * sy);
-                        const float fy = __uint_as_float(bd_rl(ydv, 2 * sy + 1));
-                        Quad v0 = q_zero(), v1 = q_zero();
-                        if ((yw >> 24) & 1u) {
-                            const uint32_t lo = yw & 0xFFFu, hi = (yw >> 12) & 0xFFFu;
-                            const uint32_t act = have ? (yw >> 26) : BD_BOTH;
-                            have = true;
-                            if ((yw >> 25) & 1u) {               // ceil row lives in set A
-                                if (act == BD_BOTH) lds_row(lo, sB);
-                                if (act != BD_REUSE) lds_row(hi, sA);
-                                v0 = q_lerp(sB.h0, sA.h0, fy); v1 = q_lerp(sB.h1, sA.h1, fy);
-                            } else {
-                                if (act == BD_BOTH) lds_row(lo, sA);
-                                if (act != BD_REUSE) lds_row(hi, sB);
-                                v0 = q_lerp(sA.h0, sB.h0, fy); v1 = q_lerp(sA.h1, sB.h1, fy);
-                            }
-                            if (!xall) {
-                                if (!ok0) v0 = q_zero();
-                                if (!ok1) v1 = q_zero();
-                            }
-                        }
-                        fold(sy, v0, v1);
+                for (int ky = 0; ky < POOL; ++ky) {
+                    const int sy = oy * POOL + ky;
+                    uint32_t yw = bd_rl(ydv, 2 * sy);
+                    const uint64_t fy = bd_rl(ydv, 2 * sy + 1);
+                    if (!have) yw = (yw & ~(3u << 26)) | (BD_BOTH << 26);
+                    have = (yw >> 24) & 1u ? true : have;
+                    const uint32_t lo = (yw & 0xFFFu) * rowpitch, hi = ((yw >> 12) & 0xFFFu) * rowpitch;
+                    Quad v0, v1;
+                    asm volatile(
+                        "s_bitcmp1_b32 %[yw], 24\n"
+                        "s_cbranch_scc0 .Lbd_zero_%=\n"
+                        "s_bitcmp1_b32 %[yw], 25\n"
+                        "s_cbranch_scc1 .Lbd_par1_%=\n"
+                        BD_ROWSTEP_HALF("0", "A", "B")
+                        "s_branch .Lbd_end_%=\n"
+                        ".Lbd_par1_%=:\n"
+                        BD_ROWSTEP_HALF("1", "B", "A")
+                        "s_branch .Lbd_end_%=\n"
+                        ".Lbd_zero_%=:\n"
+                        "v_mov_b64 %[v0a], 0\n"
+                        "v_mov_b64 %[v0b], 0\n"
+                        "v_mov_b64 %[v1a], 0\n"
+                        "v_mov_b64 %[v1b], 0\n"
+                        ".Lbd_end_%=:\n"
+                        : [v0a] "=&v"(v0.a), [v0b] "=&v"(v0.b), [v1a] "=&v"(v1.a), [v1b] "=&v"(v1.b),
+                          [A0] "+v"(sA.h0.a), [A1] "+v"(sA.h0.b), [A2] "+v"(sA.h1.a), [A3] "+v"(sA.h1.b),
+                          [B0] "+v"(sB.h0.a), [B1] "+v"(sB.h0.b), [B2] "+v"(sB.h1.a), [B3] "+v"(sB.h1.b)
+                        : [a0] "v"(la0), [a1] "v"(la1), [a2] "v"(la2), [a3] "v"(la3),
+                          [fx0] "v"(fx0p), [fx1] "v"(fx1p), [yw] "s"(yw), [lo] "s"(lo), [hi] "s"(hi),
+                          [fy] "s"(fy)
+                        : "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120",
+                          "v121", "v122", "v123", "v124", "v125", "v126", "v127", "scc");
+                    if (!xall) {
+                        if (!ok0) v0 = q_zero();
+                        if (!ok1) v1 = q_zero();
                     }
+                    fold(oy, ky, v0, v1);
                 }
             }
 
@@ -373,7 +440,7 @@ roi_fwd_band_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
                         if (!ok0) v0 = q_zero();
                         if (!ok1) v1 = q_zero();
                     }
-                    fold(sy, v0, v1);
+                    fold(sy / POOL, sy % POOL, v0, v1);
                 }
             }
             }
