@@ -235,6 +235,8 @@ roi_fwd_band_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
             *reinterpret_cast<f32x4*>(band_lds + (size_t)row * rowpitch + x * BD_CELL + part * 16) = v;
         }
     }
+    uint32_t* claim_ctr = reinterpret_cast<uint32_t*>(band_lds + (size_t)T * rowpitch + BD_LDS_RING);
+    if (threadIdx.x == 0) *claim_ctr = 0u;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 3, quad = lane & 7;
@@ -250,67 +252,55 @@ roi_fwd_band_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
     unsigned char* hdr = band_lds + (size_t)T * rowpitch + (size_t)BD_WAVES * BD_RING * BD_ENTRY +
                          (size_t)wave * BD_RING * BD_HDR;
 
-#pragma unroll 1
-    for (int base = 0; base < R; base += 64 * BD_WAVES) {
-        // lane l looks at RoI base + 16 l + wave: which of its output rows are this band's
-        const int rc = base + lane * BD_WAVES + wave;
-        uint32_t mine = 0, mine_direct = 0;
-        if (rc < R) {
-            const uint4 bw = *reinterpret_cast<const uint4*>(dimg[rc].band);
-            mine = band_match(bw, (uint32_t)k);
-            if (k == 0) mine_direct = band_match(bw, BD_DIRECT);
+    // The waves of a workgroup claim the image's RoIs eight at a time from a counter in LDS (a
+    // fixed share per wave leaves the faster waves idle for a tenth of the workgroup's time).
+    // The descriptors of the next claim are fetched into registers before the current eight are
+    // processed, whether or not this band has rows of them: nothing waits on the fetch.
+    const int sel = lane >> 4, part = lane & 15;   // piece t of a lane: part `part` of entry sel + 4 t
+    auto claim = [&]() -> int {
+        uint32_t n = 0;
+        if (lane == 0)
+            n = __hip_atomic_fetch_add(claim_ctr, (uint32_t)BD_RING, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+        return (int)bd_first(n);
+    };
+    auto fetch = [&](int n, uint4 (&piece)[2], uint4& bw) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int rr = n + sel + 4 * t;
+            piece[t] = make_uint4(0u, 0u, 0u, 0u);
+            if (rr < R)
+                piece[t] = *reinterpret_cast<const uint4*>(
+                    reinterpret_cast<const unsigned char*>(dimg + rr) + part * 16);
         }
-        unsigned long long todo = __ballot((mine | mine_direct) != 0u);
+        bw = make_uint4(0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu);
+        if (lane < BD_RING && n + lane < R) bw = *reinterpret_cast<const uint4*>(dimg[n + lane].band);
+    };
+    uint4 piece[2], bw;
+    int n_cur = claim();
+    fetch(n_cur, piece, bw);
 #pragma unroll 1
-        while (todo != 0ull) {
-            // ---- next BD_RING descriptors into the ring: piece i = lane + 64 t is part i % 16
-            // of entry i / 16
-            int lpos[BD_RING];
-            int cnt = 0;
+    while (n_cur < R) {
+        {
 #pragma unroll
-            for (int e = 0; e < BD_RING; ++e) {
-                lpos[e] = 0;
-                if (todo != 0ull) {
-                    lpos[e] = __ffsll((long long)todo) - 1;
-                    todo &= todo - 1ull;
-                    cnt = e + 1;
-                }
-            }
-            {
-                const int sel = lane >> 4, part = lane & 15;
-                uint4 piece[2];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int e = sel + 4 * t;
-                    const int l = sel == 0 ? lpos[4 * t] : sel == 1 ? lpos[4 * t + 1]
-                                : sel == 2 ? lpos[4 * t + 2] : lpos[4 * t + 3];
-                    piece[t] = make_uint4(0u, 0u, 0u, 0u);
-                    if (e < cnt)
-                        piece[t] = *reinterpret_cast<const uint4*>(
-                            reinterpret_cast<const unsigned char*>(dimg + (base + l * BD_WAVES + wave)) +
-                            part * 16);
-                }
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-                    *reinterpret_cast<uint4*>(ring + (sel + 4 * t) * BD_ENTRY + part * 16) = piece[t];
-                {
-                    // every lane takes part in the shuffles (a shuffle reads active lanes only)
-                    int l = lpos[0];
-#pragma unroll
-                    for (int e = 1; e < BD_RING; ++e) l = lane == e ? lpos[e] : l;
-                    // the rows words live in lane l of `mine` / `mine_direct`
-                    const uint32_t rw = (uint32_t)__shfl((int)mine, l);
-                    const uint32_t rd = (uint32_t)__shfl((int)mine_direct, l);
-                    if (lane < BD_RING)
-                        *reinterpret_cast<uint4*>(hdr + lane * BD_HDR) =
-                            make_uint4((uint32_t)(base + l * BD_WAVES + wave), rw, rd, 0u);
-                }
-            }
+            for (int t = 0; t < 2; ++t)
+                *reinterpret_cast<uint4*>(ring + (sel + 4 * t) * BD_ENTRY + part * 16) = piece[t];
+            const uint32_t mine = band_match(bw, (uint32_t)k);
+            const uint32_t mine_direct = k == 0 ? band_match(bw, BD_DIRECT) : 0u;
+            if (lane < BD_RING)
+                *reinterpret_cast<uint4*>(hdr + lane * BD_HDR) =
+                    make_uint4((uint32_t)(n_cur + lane), mine, mine_direct, 0u);
+        }
+        const int n_next = claim();
+        fetch(n_next, piece, bw);
+        n_cur = n_next;
+        {
 #pragma unroll 1
-            for (int vi = 0; vi < cnt; ++vi) {
+            for (int vi = 0; vi < BD_RING; ++vi) {
             const uint4 hv = *reinterpret_cast<const uint4*>(hdr + vi * BD_HDR);
             const int r = (int)bd_first(hv.x);
             const uint32_t rows = bd_first(hv.y), rows_direct = bd_first(hv.z);
+            if ((rows | rows_direct) == 0u) continue;                               // uniform
             const unsigned char* ent = ring + vi * BD_ENTRY;
             const uint32_t ydv = *reinterpret_cast<const uint32_t*>(ent + (lane & 31) * 4);
             const uint4 xdv = *reinterpret_cast<const uint4*>(ent + 128 + q * 16);
@@ -564,7 +554,7 @@ extern "C" int frcnn_roi_crop_pool_fwd_ws(const float* fmap, int B, int H, int W
     FRCNN_LAUNCH(roi_band_prep_kernel, dim3((n_roi + 255) / 256), dim3(256), 0, st,
                  reinterpret_cast<const float4*>(rois), n_roi, H, W, crop_h, crop_w, pool, plan.nb,
                  plan.S, plan.T, desc);
-    const size_t lds = (size_t)plan.T * W * BD_CELL + BD_LDS_RING;
+    const size_t lds = (size_t)plan.T * W * BD_CELL + BD_LDS_RING + 64;    // + the claim counter
     const dim3 grid((unsigned)(ngroup * plan.nb), (unsigned)B), block(64 * BD_WAVES);
 #define FRCNN_BAND(P, WN)                                                                          \
     do {                                                                                           \
