@@ -60,25 +60,15 @@ roi_band_prep_kernel(const float4* __restrict__ rois, int n_roi, int H, int W, i
     if (i >= n_roi) return;
     const float4 box = rois[i];
     RoiDesc* d = desc + i;
+    // pass 1: the band of every output row
     int rmin = 1 << 30, rmax = -1;
     uint32_t bandw[4] = {0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu};
-    int st_lo = -1, st_hi = -1;                  // rows of the previous sample row inside the image
-    uint32_t par = 0;                            // set that holds st_hi
-    for (int s = 0; s < BD_MAXCROP; ++s) {
+    for (int s = 0; s < ch; ++s) {
         int lo = 0, hi = 0, ok = 0;
         float fr = 0.f;
-        if (s < ch) axis_sample(box.x, box.z, H, ch, s, lo, hi, fr, ok);
-        uint32_t act = BD_BOTH;
-        if (ok) {
-            rmin = min(rmin, min(lo, hi)); rmax = max(rmax, max(lo, hi));
-            if (lo == st_lo && hi == st_hi) act = BD_REUSE;
-            else if (lo == st_hi) { act = BD_SHIFT; par ^= 1u; }
-            st_lo = lo; st_hi = hi;
-        }
-        d->y[2 * s] = (uint32_t)lo | ((uint32_t)hi << 12) | ((uint32_t)ok << 24) | (par << 25) |
-                      (act << 26);
-        d->y[2 * s + 1] = __float_as_uint(fr);
-        if (s < ch && s % pool == pool - 1) {    // output row p is complete
+        axis_sample(box.x, box.z, H, ch, s, lo, hi, fr, ok);
+        if (ok) { rmin = min(rmin, min(lo, hi)); rmax = max(rmax, max(lo, hi)); }
+        if (s % pool == pool - 1) {              // output row p is complete
             const int p = s / pool;
             uint32_t band = 0;                   // rows of zeros only: band 0 writes them
             if (rmax >= 0) {
@@ -88,6 +78,33 @@ roi_band_prep_kernel(const float4* __restrict__ rois, int n_roi, int H, int W, i
             bandw[p >> 2] = (bandw[p >> 2] & ~(0xFFu << (8 * (p & 3)))) | (band << (8 * (p & 3)));
             rmin = 1 << 30; rmax = -1;
         }
+    }
+    // pass 2: what the walk does per sample row.  The walk of a band starts afresh (reads both
+    // rows) at the first sample row of an output row whose band differs from the band of the
+    // output row before it; a sample row outside the image reads nothing.
+    int st_lo = -1, st_hi = -1;                  // rows of the previous sample row inside the image
+    uint32_t par = 0;                            // set that holds st_hi
+    uint32_t prev_band = BD_NONE;
+    for (int s = 0; s < BD_MAXCROP; ++s) {
+        int lo = 0, hi = 0, ok = 0;
+        float fr = 0.f;
+        if (s < ch) axis_sample(box.x, box.z, H, ch, s, lo, hi, fr, ok);
+        if (s < ch && s % pool == 0) {
+            const int p = s / pool;
+            const uint32_t band = (bandw[p >> 2] >> (8 * (p & 3))) & 0xFFu;
+            if (band != prev_band) { st_lo = -1; st_hi = -1; }
+            prev_band = band;
+        }
+        uint32_t act = BD_REUSE;
+        if (ok) {
+            act = BD_BOTH;
+            if (lo == st_lo && hi == st_hi) act = BD_REUSE;
+            else if (lo == st_hi) { act = BD_SHIFT; par ^= 1u; }
+            st_lo = lo; st_hi = hi;
+        }
+        d->y[2 * s] = (uint32_t)lo | ((uint32_t)hi << 12) | ((uint32_t)ok << 24) | (par << 25) |
+                      (act << 26);
+        d->y[2 * s + 1] = __float_as_uint(fr);
     }
     for (int s = 0; s < BD_MAXCROP; ++s) {
         int lo = 0, hi = 0, ok = 0;
@@ -152,32 +169,38 @@ __device__ __forceinline__ uint32_t band_match(uint4 w, uint32_t want) {
 // are branches inside one statement whose set operands are tied ("+v"), so the compiler sees
 // straight-line code and cannot answer the conditional writes with register copies (it did:
 // about twenty v_mov_b64 per sample row in every C++ formulation of this step).
-// v[112:127] are the staging registers of the four 16-byte LDS reads of a feature row.
+// v[96:111] and v[112:127] are the staging registers of the four 16-byte LDS reads of the
+// ceil and the floor feature row.
 // Dependent packed instructions are kept one instruction apart (gfx940-family forwarding
 // hazard of instructions that write through op_sel / packed destinations).
-#define BD_LOADROW(OFF, S)                                                                   \
-    "v_add_u32 v112, " OFF ", %[a0]\n"                                                       \
-    "v_add_u32 v116, " OFF ", %[a1]\n"                                                       \
-    "v_add_u32 v120, " OFF ", %[a2]\n"                                                       \
-    "v_add_u32 v124, " OFF ", %[a3]\n"                                                       \
-    "ds_read_b128 v[112:115], v112\n"                                                        \
-    "ds_read_b128 v[116:119], v116\n"                                                        \
-    "ds_read_b128 v[120:123], v120\n"                                                        \
-    "ds_read_b128 v[124:127], v124\n"                                                        \
-    "s_waitcnt lgkmcnt(2)\n"                                                                 \
-    "v_pk_add_f32 v[116:117], v[116:117], v[112:113] neg_lo:[0,1] neg_hi:[0,1]\n"            \
-    "v_pk_add_f32 v[118:119], v[118:119], v[114:115] neg_lo:[0,1] neg_hi:[0,1]\n"            \
-    "v_pk_mul_f32 v[116:117], %[fx0], v[116:117]\n"                                          \
-    "v_pk_mul_f32 v[118:119], %[fx0], v[118:119]\n"                                          \
-    "v_pk_add_f32 %[" S "0], v[112:113], v[116:117]\n"                                          \
-    "v_pk_add_f32 %[" S "1], v[114:115], v[118:119]\n"                                          \
-    "s_waitcnt lgkmcnt(0)\n"                                                                 \
-    "v_pk_add_f32 v[124:125], v[124:125], v[120:121] neg_lo:[0,1] neg_hi:[0,1]\n"            \
-    "v_pk_add_f32 v[126:127], v[126:127], v[122:123] neg_lo:[0,1] neg_hi:[0,1]\n"            \
-    "v_pk_mul_f32 v[124:125], %[fx1], v[124:125]\n"                                          \
-    "v_pk_mul_f32 v[126:127], %[fx1], v[126:127]\n"                                          \
-    "v_pk_add_f32 %[" S "2], v[120:121], v[124:125]\n"                                          \
-    "v_pk_add_f32 %[" S "3], v[122:123], v[126:127]\n"
+// staging registers R0..R0+15 <- the four 16-byte cells of feature row OFF (LDS byte offset)
+#define BD_ISSUE(OFF, R0, R1, R2, R3, R0A, R1A, R2A, R3A)                                    \
+    "v_add_u32 v" R0A ", " OFF ", %[a0]\n"                                                   \
+    "v_add_u32 v" R1A ", " OFF ", %[a1]\n"                                                   \
+    "v_add_u32 v" R2A ", " OFF ", %[a2]\n"                                                   \
+    "v_add_u32 v" R3A ", " OFF ", %[a3]\n"                                                   \
+    "ds_read_b128 v[" R0 "], v" R0A "\n"                                                     \
+    "ds_read_b128 v[" R1 "], v" R1A "\n"                                                     \
+    "ds_read_b128 v[" R2 "], v" R2A "\n"                                                     \
+    "ds_read_b128 v[" R3 "], v" R3A "\n"
+#define BD_ISSUE_LO(OFF) BD_ISSUE(OFF, "112:115", "116:119", "120:123", "124:127", "112", "116", "120", "124")
+#define BD_ISSUE_HI(OFF) BD_ISSUE(OFF, "96:99", "100:103", "104:107", "108:111", "96", "100", "104", "108")
+// set S <- the x-lerp of a staged row: four independent chains, dependent instructions four apart
+#define BD_XLERP(S, C0L, C0H, C1L, C1H, C2L, C2H, C3L, C3H)                                  \
+    "v_pk_add_f32 v[" C1L "], v[" C1L "], v[" C0L "] neg_lo:[0,1] neg_hi:[0,1]\n"            \
+    "v_pk_add_f32 v[" C1H "], v[" C1H "], v[" C0H "] neg_lo:[0,1] neg_hi:[0,1]\n"            \
+    "v_pk_add_f32 v[" C3L "], v[" C3L "], v[" C2L "] neg_lo:[0,1] neg_hi:[0,1]\n"            \
+    "v_pk_add_f32 v[" C3H "], v[" C3H "], v[" C2H "] neg_lo:[0,1] neg_hi:[0,1]\n"            \
+    "v_pk_mul_f32 v[" C1L "], %[fx0], v[" C1L "]\n"                                          \
+    "v_pk_mul_f32 v[" C1H "], %[fx0], v[" C1H "]\n"                                          \
+    "v_pk_mul_f32 v[" C3L "], %[fx1], v[" C3L "]\n"                                          \
+    "v_pk_mul_f32 v[" C3H "], %[fx1], v[" C3H "]\n"                                          \
+    "v_pk_add_f32 %[" S "0], v[" C0L "], v[" C1L "]\n"                                       \
+    "v_pk_add_f32 %[" S "1], v[" C0H "], v[" C1H "]\n"                                       \
+    "v_pk_add_f32 %[" S "2], v[" C2L "], v[" C3L "]\n"                                       \
+    "v_pk_add_f32 %[" S "3], v[" C2H "], v[" C3H "]\n"
+#define BD_XLERP_LO(S) BD_XLERP(S, "112:113", "114:115", "116:117", "118:119", "120:121", "122:123", "124:125", "126:127")
+#define BD_XLERP_HI(S) BD_XLERP(S, "96:97", "98:99", "100:101", "102:103", "104:105", "106:107", "108:109", "110:111")
 // v = L + (H - L) * fy for the four pairs
 #define BD_YLERP(L, H)                                                                       \
     "v_pk_add_f32 %[v0a], %[" H "0], %[" L "0] neg_lo:[0,1] neg_hi:[0,1]\n"                        \
@@ -193,19 +216,43 @@ __device__ __forceinline__ uint32_t band_match(uint4 w, uint32_t want) {
     "v_pk_add_f32 %[v1a], %[" L "2], %[v1a]\n"                                                  \
     "v_pk_add_f32 %[v1b], %[" L "3], %[v1b]\n"
 // bit 27 of the row word: both rows are new; bit 26: the ceil row is new; bit 25: the ceil row
-// lives in set A; bit 24 clear: the sample row lies outside the image (zeros)
+// lives in set A; bit 24 clear: the sample row lies outside the image (zeros, nothing read).
+// The reads of a sample row are issued one row ahead (BD_ISSUE_NEXT, from the NEXT row's word
+// %[ywn] and row offsets) right after the staged cells of the current row have been consumed,
+// so their latency passes behind the current row's y-lerp, its pooling and the next row's
+// scalar decode.  The staging registers are operands pinned to v[96:127]: they stay live from
+// one statement to the next.
+#define BD_ISSUE_NEXT(TAG)                                                                   \
+    "s_bitcmp1_b32 %[ywn], 27\n"                                                             \
+    "s_cbranch_scc0 .Lbd_n1" TAG "_%=\n"                                                     \
+    BD_ISSUE_LO("%[lon]")                                                                    \
+    BD_ISSUE_HI("%[hin]")                                                                    \
+    "s_branch .Lbd_n0" TAG "_%=\n"                                                           \
+    ".Lbd_n1" TAG "_%=:\n"                                                                   \
+    "s_bitcmp1_b32 %[ywn], 26\n"                                                             \
+    "s_cbranch_scc0 .Lbd_n0" TAG "_%=\n"                                                     \
+    BD_ISSUE_HI("%[hin]")                                                                    \
+    ".Lbd_n0" TAG "_%=:\n"
 #define BD_ROWSTEP_HALF(TAG, SETLO, SETHI)                                                   \
     "s_bitcmp1_b32 %[yw], 27\n"                                                              \
     "s_cbranch_scc0 .Lbd_one" TAG "_%=\n"                                                    \
-    BD_LOADROW("%[lo]", SETLO)                                                              \
-    "s_branch .Lbd_hi" TAG "_%=\n"                                                           \
+    "s_waitcnt lgkmcnt(0)\n"                                                                 \
+    BD_XLERP_LO(SETLO)                                                                       \
+    BD_XLERP_HI(SETHI)                                                                       \
+    "s_branch .Lbd_nx" TAG "_%=\n"                                                           \
     ".Lbd_one" TAG "_%=:\n"                                                                  \
     "s_bitcmp1_b32 %[yw], 26\n"                                                              \
-    "s_cbranch_scc0 .Lbd_lerp" TAG "_%=\n"                                                   \
-    ".Lbd_hi" TAG "_%=:\n"                                                                   \
-    BD_LOADROW("%[hi]", SETHI)                                                              \
-    ".Lbd_lerp" TAG "_%=:\n"                                                                 \
+    "s_cbranch_scc0 .Lbd_nx" TAG "_%=\n"                                                     \
+    "s_waitcnt lgkmcnt(0)\n"                                                                 \
+    BD_XLERP_HI(SETHI)                                                                       \
+    ".Lbd_nx" TAG "_%=:\n"                                                                   \
+    BD_ISSUE_NEXT(TAG)                                                                       \
+    "s_bitcmp1_b32 %[yw], 24\n"                                                              \
+    "s_cbranch_scc0 .Lbd_zero_%=\n"                                                          \
     BD_YLERP(SETLO, SETHI)
+#define BD_STAGING(c)                                                                        \
+    "+{v[96:99]}"(c[0]), "+{v[100:103]}"(c[1]), "+{v[104:107]}"(c[2]), "+{v[108:111]}"(c[3]),  \
+    "+{v[112:115]}"(c[4]), "+{v[116:119]}"(c[5]), "+{v[120:123]}"(c[6]), "+{v[124:127]}"(c[7])
 
 // The lerped feature rows a wave holds: two register sets, feature row r lives in set r & 1.
 // A sample row's floor and ceil rows are neighbours, so they never compete for a set, and a
@@ -217,10 +264,20 @@ template <int POOL, bool WIN>
 __global__ void __launch_bounds__(64 * BD_WAVES)
 roi_fwd_band_kernel(const float* __restrict__ fmap, int H, int W, int C, long long sb, long long sh,
                     long long sw, const RoiDesc* __restrict__ desc, int R, int ch, int cw,
-                    int ngroup, int S, int T, float* __restrict__ out,
-                    uint8_t* __restrict__ winner) {
+                    int ngroup, int nband, int nimg, int S, int T, float* __restrict__ out,
+                    uint8_t* __restrict__ winner, int dbg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char band_lds[];
-    const int g = blockIdx.x % ngroup, k = blockIdx.x / ngroup, b = blockIdx.y;
+    // Workgroup n runs on XCD n % 8 (each XCD has its own L2).  The ngroup channel groups of one
+    // (image, band) are given to one XCD at consecutive times: that L2 then sees all the 128-byte
+    // pieces of an output bin (and of a descriptor) instead of an eighth of them.
+    int g, k, b;
+    {
+        const int n = (int)blockIdx.x, J = nimg * nband, full = J & ~7;
+        int j;
+        if (n < full * ngroup) { j = 8 * ((n >> 3) / ngroup) + (n & 7); g = (n >> 3) % ngroup; }
+        else { const int m = n - full * ngroup; j = full + m / ngroup; g = m % ngroup; }
+        b = j / nband; k = j - b * nband;
+    }
     const int r0 = k * S, r1 = min(r0 + T, H);
     const uint32_t rowpitch = (uint32_t)W * BD_CELL;
     const float* img = fmap + (size_t)b * sb + (size_t)g * BD_CG;
@@ -244,9 +301,9 @@ roi_fwd_band_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
     const bool live0 = 2 * q < cw, live1 = 2 * q + 1 < cw;      // this lane's two sample columns
     const RoiDesc* dimg = desc + (size_t)b * R;
     const size_t bin_stride = (size_t)C;                         // floats between output columns
-    const uint32_t lds_adj = (uint32_t)quad * 16u - (uint32_t)r0 * rowpitch;
     // byte address of the band inside the LDS (what a ds_read takes)
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)band_lds;
+    const uint32_t lds_adj = lds_base + (uint32_t)quad * 16u - (uint32_t)r0 * rowpitch;
     // this wave's descriptor ring (private: no barrier, LDS operations of a wave stay in order)
     unsigned char* ring = band_lds + (size_t)T * rowpitch + (size_t)wave * BD_RING * BD_ENTRY;
     unsigned char* hdr = band_lds + (size_t)T * rowpitch + (size_t)BD_WAVES * BD_RING * BD_ENTRY +
@@ -276,6 +333,9 @@ roi_fwd_band_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
         bw = make_uint4(0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu);
         if (lane < BD_RING && n + lane < R) bw = *reinterpret_cast<const uint4*>(dimg[n + lane].band);
     };
+    f32x4 stg[8];                                // cells of a feature row on their way to a row set
+#pragma unroll
+    for (int i = 0; i < 8; ++i) stg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     uint4 piece[2], bw;
     int n_cur = claim();
     fetch(n_cur, piece, bw);
@@ -295,27 +355,39 @@ roi_fwd_band_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
         fetch(n_next, piece, bw);
         n_cur = n_next;
         {
+            // header and descriptor words of ring entry vi are read while entry vi - 1 is processed
+            uint4 hv_n = *reinterpret_cast<const uint4*>(hdr);
+            uint32_t ydv_n = *reinterpret_cast<const uint32_t*>(ring + (lane & 31) * 4);
+            uint4 xdv_n = *reinterpret_cast<const uint4*>(ring + 128 + q * 16);
 #pragma unroll 1
             for (int vi = 0; vi < BD_RING; ++vi) {
-            const uint4 hv = *reinterpret_cast<const uint4*>(hdr + vi * BD_HDR);
+            const uint4 hv = hv_n;
+            uint32_t ydv = ydv_n;
+            const uint4 xdv = xdv_n;
+            {
+                const int vn = (vi + 1) & (BD_RING - 1);
+                hv_n = *reinterpret_cast<const uint4*>(hdr + vn * BD_HDR);
+                ydv_n = *reinterpret_cast<const uint32_t*>(ring + vn * BD_ENTRY + (lane & 31) * 4);
+                xdv_n = *reinterpret_cast<const uint4*>(ring + vn * BD_ENTRY + 128 + q * 16);
+            }
             const int r = (int)bd_first(hv.x);
             const uint32_t rows = bd_first(hv.y), rows_direct = bd_first(hv.z);
             if ((rows | rows_direct) == 0u) continue;                               // uniform
-            const unsigned char* ent = ring + vi * BD_ENTRY;
-            const uint32_t ydv = *reinterpret_cast<const uint32_t*>(ent + (lane & 31) * 4);
-            const uint4 xdv = *reinterpret_cast<const uint4*>(ent + 128 + q * 16);
             const uint32_t xlo0 = xdv.x & 0xFFFu, xhi0 = (xdv.x >> 12) & 0xFFFu;
             const uint32_t xlo1 = xdv.z & 0xFFFu, xhi1 = (xdv.z >> 12) & 0xFFFu;
             const bool ok0 = live0 && ((xdv.x >> 24) & 1u), ok1 = live1 && ((xdv.z >> 24) & 1u);
             const float fx0 = __uint_as_float(xdv.y), fx1 = __uint_as_float(xdv.w);
-            const bool xall = __all((ok0 || !live0) && (ok1 || !live1));
+            // lanes whose sample column lies outside the image: their samples are zeros
+            const uint64_t xout0 = __ballot(live0 && !ok0), xout1 = __ballot(live1 && !ok1);
             const uint32_t a0 = xlo0 * BD_CELL + lds_adj, a1 = xhi0 * BD_CELL + lds_adj;
             const uint32_t a2 = xlo1 * BD_CELL + lds_adj, a3 = xhi1 * BD_CELL + lds_adj;
             float* oroi = out + ((size_t)b * R + r) * (size_t)(PH * PW) * C + (size_t)g * BD_CG + quad * 4;
             uint8_t* wroi = WIN ? winner + ((size_t)b * R + r) * (size_t)(PH * PW) * C +
                                       (size_t)g * BD_CG + quad * 4 : nullptr;
             RowSet sA, sB;
-            sA.h0 = sA.h1 = sB.h0 = sB.h1 = q_zero();
+            // no initial value: the first sample row of a walk reads both of its rows
+            asm volatile("" : "=v"(sA.h0.a), "=v"(sA.h0.b), "=v"(sA.h1.a), "=v"(sA.h1.b),
+                              "=v"(sB.h0.a), "=v"(sB.h0.b), "=v"(sB.h1.a), "=v"(sB.h1.b));
             Quad best = q_zero();
             uchar4 arg = make_uchar4(0, 0, 0, 0);
 
@@ -349,60 +421,81 @@ roi_fwd_band_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
                     best.a.x = vmax3(best.a.x, v0.a.x, v1.a.x); best.a.y = vmax3(best.a.y, v0.a.y, v1.a.y);
                     best.b.x = vmax3(best.b.x, v0.b.x, v1.b.x); best.b.y = vmax3(best.b.y, v0.b.y, v1.b.y);
                 }
-                if (ky == POOL - 1 && q < PW) {
+                if (ky == POOL - 1 && q < PW && !(dbg & 1)) {
                     const size_t o = ((size_t)oy * PW + q) * bin_stride;
                     *reinterpret_cast<f32x4*>(oroi + o) = q_pack(best);
                     if (WIN) *reinterpret_cast<uchar4*>(wroi + o) = arg;
                 }
             };
             const f32x2 fx0p = {fx0, fx0}, fx1p = {fx1, fx1};
-            const uint32_t la0 = a0 + lds_base, la1 = a1 + lds_base, la2 = a2 + lds_base,
-                           la3 = a3 + lds_base;
-            bool have = false;                   // the sets hold the previous sample row's rows
-#pragma unroll 1
-            for (int oy = 0; oy < PH; ++oy) {
-                if (!((rows >> oy) & 1u)) {                                         // uniform
-                    have = false;
-                    continue;
+            const uint32_t la0 = a0, la1 = a1, la2 = a2, la3 = a3;
+            if (rows != 0u) {
+                // the descriptor words are read by lane index from here on: nothing may wait on
+                // the LDS counter inside the walk (the next row's reads are in flight there)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ydv));
+                uint32_t rem = rows;
+                int oy = __builtin_ctz(rem);
+                uint32_t ywn = bd_rl(ydv, 2 * (oy * POOL));
+                {
+                    const uint32_t lon = (ywn & 0xFFFu) * rowpitch, hin = ((ywn >> 12) & 0xFFFu) * rowpitch;
+                    asm volatile(BD_ISSUE_NEXT("p")
+                                 : BD_STAGING(stg)
+                                 : [a0] "v"(la0), [a1] "v"(la1), [a2] "v"(la2), [a3] "v"(la3),
+                                   [ywn] "s"(ywn), [lon] "s"(lon), [hin] "s"(hin)
+                                 : "scc");
                 }
+#pragma unroll 1
+                while (true) {
+                    rem &= rem - 1u;
+                    const int oyn = rem != 0u ? __builtin_ctz(rem) : 0;
 #pragma unroll
-                for (int ky = 0; ky < POOL; ++ky) {
-                    const int sy = oy * POOL + ky;
-                    uint32_t yw = bd_rl(ydv, 2 * sy);
-                    const uint64_t fy = bd_rl(ydv, 2 * sy + 1);
-                    if (!have) yw = (yw & ~(3u << 26)) | (BD_BOTH << 26);
-                    have = (yw >> 24) & 1u ? true : have;
-                    const uint32_t lo = (yw & 0xFFFu) * rowpitch, hi = ((yw >> 12) & 0xFFFu) * rowpitch;
-                    Quad v0, v1;
-                    asm volatile(
-                        "s_bitcmp1_b32 %[yw], 24\n"
-                        "s_cbranch_scc0 .Lbd_zero_%=\n"
-                        "s_bitcmp1_b32 %[yw], 25\n"
-                        "s_cbranch_scc1 .Lbd_par1_%=\n"
-                        BD_ROWSTEP_HALF("0", "A", "B")
-                        "s_branch .Lbd_end_%=\n"
-                        ".Lbd_par1_%=:\n"
-                        BD_ROWSTEP_HALF("1", "B", "A")
-                        "s_branch .Lbd_end_%=\n"
-                        ".Lbd_zero_%=:\n"
-                        "v_mov_b64 %[v0a], 0\n"
-                        "v_mov_b64 %[v0b], 0\n"
-                        "v_mov_b64 %[v1a], 0\n"
-                        "v_mov_b64 %[v1b], 0\n"
-                        ".Lbd_end_%=:\n"
-                        : [v0a] "=&v"(v0.a), [v0b] "=&v"(v0.b), [v1a] "=&v"(v1.a), [v1b] "=&v"(v1.b),
-                          [A0] "+v"(sA.h0.a), [A1] "+v"(sA.h0.b), [A2] "+v"(sA.h1.a), [A3] "+v"(sA.h1.b),
-                          [B0] "+v"(sB.h0.a), [B1] "+v"(sB.h0.b), [B2] "+v"(sB.h1.a), [B3] "+v"(sB.h1.b)
-                        : [a0] "v"(la0), [a1] "v"(la1), [a2] "v"(la2), [a3] "v"(la3),
-                          [fx0] "v"(fx0p), [fx1] "v"(fx1p), [yw] "s"(yw), [lo] "s"(lo), [hi] "s"(hi),
-                          [fy] "s"(fy)
-                        : "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120",
-                          "v121", "v122", "v123", "v124", "v125", "v126", "v127", "scc");
-                    if (!xall) {
-                        if (!ok0) v0 = q_zero();
-                        if (!ok1) v1 = q_zero();
+                    for (int ky = 0; ky < POOL; ++ky) {
+                        const int sy = oy * POOL + ky;
+                        const uint32_t yw = ywn;
+                        const uint64_t fy = bd_rl(ydv, 2 * sy + 1);
+                        if (ky < POOL - 1) ywn = bd_rl(ydv, 2 * (sy + 1));
+                        else ywn = rem != 0u ? bd_rl(ydv, 2 * (oyn * POOL)) : 0u;
+                        const uint32_t lon = (ywn & 0xFFFu) * rowpitch, hin = ((ywn >> 12) & 0xFFFu) * rowpitch;
+                        Quad v0, v1;
+                        uint64_t exec_tmp;
+                        asm volatile(
+                            "s_bitcmp1_b32 %[yw], 25\n"
+                            "s_cbranch_scc1 .Lbd_par1_%=\n"
+                            BD_ROWSTEP_HALF("0", "A", "B")
+                            "s_branch .Lbd_mask_%=\n"
+                            ".Lbd_par1_%=:\n"
+                            BD_ROWSTEP_HALF("1", "B", "A")
+                            ".Lbd_mask_%=:\n"
+                            "s_or_b64 %[tmp], %[xout0], %[xout1]\n"
+                            "s_cbranch_scc0 .Lbd_end_%=\n"
+                            "s_mov_b64 %[tmp], exec\n"
+                            "s_and_b64 exec, %[tmp], %[xout0]\n"
+                            "v_mov_b64 %[v0a], 0\n"
+                            "v_mov_b64 %[v0b], 0\n"
+                            "s_and_b64 exec, %[tmp], %[xout1]\n"
+                            "v_mov_b64 %[v1a], 0\n"
+                            "v_mov_b64 %[v1b], 0\n"
+                            "s_mov_b64 exec, %[tmp]\n"
+                            "s_branch .Lbd_end_%=\n"
+                            ".Lbd_zero_%=:\n"
+                            "v_mov_b64 %[v0a], 0\n"
+                            "v_mov_b64 %[v0b], 0\n"
+                            "v_mov_b64 %[v1a], 0\n"
+                            "v_mov_b64 %[v1b], 0\n"
+                            ".Lbd_end_%=:\n"
+                            : [v0a] "=&v"(v0.a), [v0b] "=&v"(v0.b), [v1a] "=&v"(v1.a), [v1b] "=&v"(v1.b),
+                              [A0] "+v"(sA.h0.a), [A1] "+v"(sA.h0.b), [A2] "+v"(sA.h1.a), [A3] "+v"(sA.h1.b),
+                              [B0] "+v"(sB.h0.a), [B1] "+v"(sB.h0.b), [B2] "+v"(sB.h1.a), [B3] "+v"(sB.h1.b),
+                              BD_STAGING(stg), [tmp] "=&s"(exec_tmp)
+                            : [a0] "v"(la0), [a1] "v"(la1), [a2] "v"(la2), [a3] "v"(la3),
+                              [fx0] "v"(fx0p), [fx1] "v"(fx1p), [yw] "s"(yw), [fy] "s"(fy),
+                              [ywn] "s"(ywn), [lon] "s"(lon), [hin] "s"(hin),
+                              [xout0] "s"(xout0), [xout1] "s"(xout1)
+                            : "scc");
+                        fold(oy, ky, v0, v1);
                     }
-                    fold(oy, ky, v0, v1);
+                    if (rem == 0u) break;
+                    oy = oyn;
                 }
             }
 
@@ -555,15 +648,15 @@ extern "C" int frcnn_roi_crop_pool_fwd_ws(const float* fmap, int B, int H, int W
                  reinterpret_cast<const float4*>(rois), n_roi, H, W, crop_h, crop_w, pool, plan.nb,
                  plan.S, plan.T, desc);
     const size_t lds = (size_t)plan.T * W * BD_CELL + BD_LDS_RING + 64;    // + the claim counter
-    const dim3 grid((unsigned)(ngroup * plan.nb), (unsigned)B), block(64 * BD_WAVES);
+    const dim3 grid((unsigned)((long long)ngroup * plan.nb * B)), block(64 * BD_WAVES);
 #define FRCNN_BAND(P, WN)                                                                          \
     do {                                                                                           \
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(roi_fwd_band_kernel<P, WN>),         \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
             return FRCNN_E_LAUNCH;                                                                 \
         FRCNN_LAUNCH((roi_fwd_band_kernel<P, WN>), grid, block, lds, st, fmap, H, W, C,            \
-                     (long long)sb, (long long)sh, (long long)sw, desc, R, crop_h, crop_w, ngroup, \
-                     plan.S, plan.T, out, winner);                                                 \
+                     (long long)sb, (long long)sh, (long long)sw, desc, R, crop_h, crop_w, ngroup, plan.nb, B, \
+                     plan.S, plan.T, out, winner, getenv("BD_DBG") ? atoi(getenv("BD_DBG")) : 0);  \
     } while (0)
     if (pool == 2) { if (winner) FRCNN_BAND(2, true); else FRCNN_BAND(2, false); }
     else           { FRCNN_BAND(1, false); }

@@ -29,16 +29,23 @@ if PLANAR != "0":
     fmap = fmap.permute(0, 3, 1, 2).contiguous().permute(0, 2, 3, 1)
     ws = torch.empty(ops.roi_fwd_workspace_bytes(B, cfg.post_n, (cfg.H, cfg.W, 512)),
                      dtype=torch.uint8, device=dev) if PLANAR == "1" else None
+ROI_R = int(os.environ.get("ROI_R", "0"))           # > 0: only the first ROI_R proposals per image
+proposed, pooled = path.proposed, path.pooled
+if ROI_R > 0:
+    proposed = proposed[:, :ROI_R].contiguous()
+    pooled = torch.empty((B, ROI_R) + tuple(pooled.shape[2:]), dtype=pooled.dtype, device=dev)
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 ts = []
 for _ in range(REPS):
     ev0.record()
-    ops.roi_crop_pool_fwd(fmap, path.proposed, cfg.crop, cfg.pool, want_winner=WINNER,
-                          out=path.pooled, workspace=ws)
+    ops.roi_crop_pool_fwd(fmap, proposed, cfg.crop, cfg.pool, want_winner=WINNER,
+                          out=pooled, workspace=ws)
     ev1.record()
     torch.cuda.synchronize()
     ts.append(ev0.elapsed_time(ev1))
 alg = bench.algorithmic_bytes_roi(cfg, 512, B)
+if ROI_R > 0:
+    alg = alg * ROI_R // cfg.post_n
 best = min(ts)
 print(f"roi fwd B={B} band={int(BAND)} planar={PLANAR}: min {best:.3f} ms  mean {sum(ts)/len(ts):.3f} ms  "
       f"{alg/best/1e6:.1f} GB/s algorithmic ({alg/best/1e6/8000*100:.1f}% of 8 TB/s)")
