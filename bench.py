@@ -250,9 +250,14 @@ def kernel_table(path, cfg, B, C, fmap, score, coord, gt, label, device):
             B * (N * 4 + K * 16 + K * 8 + K * 16))
     add("nms (mask + scan kernels)", lambda: ops.nms(path.cand, cfg.nms_thr, R, workspace=path.nms_ws),
         B * (K * 16 + R * 20))
-    add("roi_fwd_stage_kernel<2,false>",
-        lambda: ops.roi_crop_pool_fwd(fmap, path.proposed, cfg.crop, cfg.pool, out=path.pooled),
+    add(ops.roi_fwd_kernel_name(B, cfg.H, cfg.W, C, R, cfg.crop, cfg.pool),
+        lambda: ops.roi_crop_pool_fwd(fmap, path.proposed, cfg.crop, cfg.pool, out=path.pooled,
+                                      workspace=path.roi_ws),
         algorithmic_bytes_roi(cfg, C, B))
+    if ops.roi_fwd_kernel_name(B, cfg.H, cfg.W, C, R, cfg.crop, cfg.pool).startswith("roi_fwd_band"):
+        add("roi_fwd_stage_kernel<2,false> (per-RoI kernel, not in the step)",
+            lambda: ops.roi_crop_pool_fwd(fmap, path.proposed, cfg.crop, cfg.pool, out=path.pooled),
+            algorithmic_bytes_roi(cfg, C, B))
     add("label_proposals_kernel", lambda: ops.label_proposals(path.proposed, gt, label, cfg.fg_thr,
                                                               cfg.iou_floor, cfg.bg_label,
                                                               cfg.num_classes),
@@ -390,8 +395,10 @@ def main():
                                                 workspace=path.nms_ws), device)
         nms_cl_kept = cl_out[2].float().mean().item()
         roi_alone_ms = timed_alone(lambda: ops.roi_crop_pool_fwd(fmap, path.proposed, cfg.crop,
-                                                                 cfg.pool, out=path.pooled),
-                                   device, reps=4)
+                                                                 cfg.pool, out=path.pooled,
+                                                                 workspace=path.roi_ws),
+                                   device, reps=6)
+        roi_kernel = ops.roi_fwd_kernel_name(B, cfg.H, cfg.W, C, cfg.post_n, cfg.crop, cfg.pool)
         kernels = kernel_table(path, cfg, B, C, fmap, score, coord, gt, label, device) \
             if not args.inference else None
         alg = algorithmic_bytes_roi(cfg, C, B)
@@ -401,9 +408,10 @@ def main():
         if os.path.exists(tf):
             with open(tf) as fh:
                 rec = json.load(fh)
-            if rec.get("batch") == B and rec.get("channels") == C and args.config == "600x1000":
-                traffic = rec.get("hbm_bytes_per_launch")
-                bounds = rec.get("co_bounds")
+            if rec.get("batch") == B and rec.get("channels") == C and args.config == rec.get("config"):
+                krec = rec.get("kernels", {}).get(roi_kernel, {})
+                traffic = krec.get("hbm_bytes_per_launch")
+                bounds = krec.get("co_bounds")
         lf = os.path.join(ROOT, "profiles", "lds_bank_conflicts.json")
         if os.path.exists(lf):
             with open(lf) as fh:
@@ -437,7 +445,7 @@ def main():
             },
             "verified": verified,
             "roofline": {
-                "kernel": "roi_fwd_stage_kernel<2,false>",
+                "kernel": roi_kernel,
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,

@@ -187,16 +187,22 @@ int frcnn_roi_crop_pool_fwd(const float* fmap, int B, int H, int W, int C,
  * kernel: a workgroup keeps a band of one image's feature rows for 32 channels in LDS and
  * serves every RoI of the image from there, so the feature map enters each compute unit once
  * instead of once per RoI (module/model.py:53-55 and :30 as above; same results bit for bit).
- * Opt-in: taken only when the environment variable FRCNN_ROI_BAND_MIN_WG = n is set, the call
- * has at least n workgroups (B * C/32 * bands), the layout is channels-last with C % 32 == 0 and
- * crop <= 16 x 16; every other call is forwarded to frcnn_roi_crop_pool_fwd, so the entry
- * point accepts whatever that one accepts (on the 600x1000 workload the per-RoI kernel is the
- * faster one: 4.0 ms against 4.6 ms at B = 64).
+ * Taken when the call has at least 768 workgroups (B * C/32 * bands: three per compute unit)
+ * and at least 1024 RoIs per image, the layout is channels-last with C % 32 == 0 and the crop at
+ * most 16 x 16; every other call is forwarded to frcnn_roi_crop_pool_fwd, so the entry point
+ * accepts whatever that one accepts.  On the 600x1000 workload (C = 512, R = 2000) the band
+ * kernel takes 3.4 ms per 64 images against 3.9 ms for the per-RoI kernel, and loses below 16
+ * images per call.  The environment variable FRCNN_ROI_BAND_MIN_WG = n replaces the workgroup
+ * threshold and lifts the RoI threshold (n < 0: never).  frcnn_roi_fwd_plan tells which kernel
+ * a call with a channels-last, 16-byte aligned map and a full workspace would run (1: band,
+ * 0: per RoI).
  * Planar feature maps ([B,C,H,W] contiguous, i.e. sw == 1, sh == W, sc == H*W, sb == C*H*W): when
  * the workspace holds B*H*W*C*4 bytes beyond frcnn_roi_fwd_workspace_bytes(B,R), the map is
  * transposed into it once (frcnn_nchw_to_nhwc) and the channels-last kernels run on the copy;
  * with a smaller workspace the any-stride kernel runs on the original. */
 size_t frcnn_roi_fwd_workspace_bytes(int B, int R);
+int frcnn_roi_fwd_plan(int B, int H, int W, int C, int R, int crop_h, int crop_w, int pool,
+                       int want_winner);
 int frcnn_roi_crop_pool_fwd_ws(const float* fmap, int B, int H, int W, int C,
                                int64_t sb, int64_t sh, int64_t sw, int64_t sc,
                                const float* rois, int R, int crop_h, int crop_w, int pool,

@@ -56,6 +56,7 @@ _SIGS = {
     "frcnn_roi_crop_pool_fwd": (_i, [_p, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _p, _i, _i, _i,
                                      _i, _p, _p, _p]),
     "frcnn_roi_fwd_workspace_bytes": (_sz, [_i, _i]),
+    "frcnn_roi_fwd_plan": (_i, [_i] * 9),
     "frcnn_roi_crop_pool_fwd_ws": (_i, [_p, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _p, _i, _i, _i,
                                         _i, _p, _p, _p, _sz, _p]),
     "frcnn_nchw_to_nhwc": (_i, [_p, _i, _i, _i, _i, _p, _p]),

@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(64 * BD_WAVES)
 roi_fwd_band_kernel(const float* __restrict__ fmap, int H, int W, int C, long long sb, long long sh,
                     long long sw, const RoiDesc* __restrict__ desc, int R, int ch, int cw,
                     int ngroup, int nband, int nimg, int S, int T, float* __restrict__ out,
-                    uint8_t* __restrict__ winner, int dbg) {
+                    uint8_t* __restrict__ winner) {
     extern __shared__ __attribute__((aligned(16))) unsigned char band_lds[];
     // Workgroup n runs on XCD n % 8 (each XCD has its own L2).  The ngroup channel groups of one
     // (image, band) are given to one XCD at consecutive times: that L2 then sees all the 128-byte
@@ -281,15 +281,28 @@ roi_fwd_band_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
     const int r0 = k * S, r1 = min(r0 + T, H);
     const uint32_t rowpitch = (uint32_t)W * BD_CELL;
     const float* img = fmap + (size_t)b * sb + (size_t)g * BD_CG;
-    // ---- the band: [row][x][32 channels]
+    // ---- the band: [row][x][32 channels]; eight 16-byte parts per thread in flight at a time
     {
         const int nparts = (r1 - r0) * W * (BD_CELL / 16);
-        for (int idx = threadIdx.x; idx < nparts; idx += 64 * BD_WAVES) {
-            const int cell = idx >> 3, part = idx & 7;
-            const int row = cell / W, x = cell - row * W;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(img + (size_t)(r0 + row) * sh +
-                                                            (size_t)x * sw + part * 4);
-            *reinterpret_cast<f32x4*>(band_lds + (size_t)row * rowpitch + x * BD_CELL + part * 16) = v;
+        constexpr int U = 8;
+#pragma unroll 1
+        for (int base = threadIdx.x; base < nparts; base += 64 * BD_WAVES * U) {
+            f32x4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = base + u * 64 * BD_WAVES;
+                if (idx < nparts) {
+                    const int cell = idx >> 3, part = idx & 7;
+                    const int row = cell / W, x = cell - row * W;
+                    v[u] = *reinterpret_cast<const f32x4*>(img + (size_t)(r0 + row) * sh + (size_t)x * sw +
+                                                           part * 4);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = base + u * 64 * BD_WAVES;
+                if (idx < nparts) *reinterpret_cast<f32x4*>(band_lds + (size_t)idx * 16) = v[u];
+            }
         }
     }
     uint32_t* claim_ctr = reinterpret_cast<uint32_t*>(band_lds + (size_t)T * rowpitch + BD_LDS_RING);
@@ -421,7 +434,7 @@ roi_fwd_band_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
                     best.a.x = vmax3(best.a.x, v0.a.x, v1.a.x); best.a.y = vmax3(best.a.y, v0.a.y, v1.a.y);
                     best.b.x = vmax3(best.b.x, v0.b.x, v1.b.x); best.b.y = vmax3(best.b.y, v0.b.y, v1.b.y);
                 }
-                if (ky == POOL - 1 && q < PW && !(dbg & 1)) {
+                if (ky == POOL - 1 && q < PW) {
                     const size_t o = ((size_t)oy * PW + q) * bin_stride;
                     *reinterpret_cast<f32x4*>(oroi + o) = q_pack(best);
                     if (WIN) *reinterpret_cast<uchar4*>(wroi + o) = arg;
@@ -584,6 +597,32 @@ extern "C" size_t frcnn_roi_fwd_workspace_bytes(int B, int R) {
     return roi_ws_align((size_t)B * R * sizeof(RoiDesc));
 }
 
+// Which forward kernel a channels-last call is given (alignment and workspace aside).
+// The band kernel wins once its workgroups (B * C/32 * bands, one per CU at a time) fill the
+// chip about three times over: on the 600x1000 workload (C = 512, R = 2000, 3 bands) it takes
+// 0.98 / 1.79 / 3.38 ms at B = 16 / 32 / 64 against 1.02 / 1.94 / 3.92 ms for the per-RoI
+// kernel, and loses below (0.56 vs 0.52 ms at B = 8).  A band is loaded once per workgroup
+// whatever R is: below about a thousand RoIs per image the per-RoI kernel is the faster one.
+// FRCNN_ROI_BAND_MIN_WG = n replaces the first threshold and lifts the second (n < 0: never).
+static bool band_wanted(int B, int H, int W, int C, int R, int crop_h, int crop_w, int pool,
+                        bool want_winner) {
+    if (C % BD_CG || (pool != 1 && pool != 2) || crop_h % pool || crop_w % pool) return false;
+    const BandPlan plan = band_plan(H, W, crop_h, pool);
+    long long min_wg = 768;
+    int min_roi = 1024;
+    if (const char* e = getenv("FRCNN_ROI_BAND_MIN_WG")) { min_wg = atoll(e); min_roi = 1; }
+    return plan.ok && crop_h <= BD_MAXCROP && crop_w <= BD_MAXCROP && H < 4096 && W < 4096 &&
+           min_wg >= 0 && (long long)B * (C / BD_CG) * plan.nb >= min_wg &&
+           (long long)B * (C / BD_CG) * plan.nb <= 0x7FFFFFFFll && R >= min_roi &&
+           !(pool == 1 && want_winner);
+}
+
+extern "C" int frcnn_roi_fwd_plan(int B, int H, int W, int C, int R, int crop_h, int crop_w, int pool,
+                                  int want_winner) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || R <= 0 || crop_h <= 0 || crop_w <= 0) return 0;
+    return band_wanted(B, H, W, C, R, crop_h, crop_w, pool, want_winner != 0) ? 1 : 0;
+}
+
 extern "C" int frcnn_nchw_to_nhwc(const float* src, int B, int C, int H, int W, float* dst,
                                   frcnn_stream_t stream) {
     if (!src || !dst || src == dst || B <= 0 || C <= 0 || H <= 0 || W <= 0) return FRCNN_E_BADARG;
@@ -627,15 +666,7 @@ extern "C" int frcnn_roi_crop_pool_fwd_ws(const float* fmap, int B, int H, int W
                          (!winner || (reinterpret_cast<uintptr_t>(winner) % 4) == 0);
     const BandPlan plan = band_plan(H, W, crop_h, pool);
     const int ngroup = C / BD_CG;
-    // The band kernel is opt-in: on the 600x1000 workload (B = 64, C = 512, R = 2000) it takes
-    // 4.6 ms against 4.0 ms for the per-RoI kernel although it issues 40 times fewer vector
-    // loads -- both are bound by instruction issue, not by memory.  FRCNN_ROI_BAND_MIN_WG = n
-    // enables it for calls with at least n workgroups (B * C/32 * bands; 192 fills the chip).
-    long long min_wg = -1;
-    if (const char* e = getenv("FRCNN_ROI_BAND_MIN_WG")) min_wg = atoll(e);
-    const bool band_path = aligned && plan.ok && crop_h <= BD_MAXCROP && crop_w <= BD_MAXCROP &&
-                           H < 4096 && W < 4096 && B <= 65535 &&
-                           min_wg >= 0 && (long long)B * ngroup * plan.nb >= min_wg && !(pool == 1 && winner) &&
+    const bool band_path = aligned && band_wanted(B, H, W, C, R, crop_h, crop_w, pool, winner != nullptr) &&
                            workspace && workspace_bytes >= frcnn_roi_fwd_workspace_bytes(B, R) &&
                            (reinterpret_cast<uintptr_t>(workspace) % 16) == 0;
     if (!band_path)
@@ -656,7 +687,7 @@ extern "C" int frcnn_roi_crop_pool_fwd_ws(const float* fmap, int B, int H, int W
             return FRCNN_E_LAUNCH;                                                                 \
         FRCNN_LAUNCH((roi_fwd_band_kernel<P, WN>), grid, block, lds, st, fmap, H, W, C,            \
                      (long long)sb, (long long)sh, (long long)sw, desc, R, crop_h, crop_w, ngroup, plan.nb, B, \
-                     plan.S, plan.T, out, winner, getenv("BD_DBG") ? atoi(getenv("BD_DBG")) : 0);  \
+                     plan.S, plan.T, out, winner);                                                 \
     } while (0)
     if (pool == 2) { if (winner) FRCNN_BAND(2, true); else FRCNN_BAND(2, false); }
     else           { FRCNN_BAND(1, false); }

@@ -225,6 +225,15 @@ def roi_fwd_workspace_bytes(B: int, R: int, planar_shape: Optional[Tuple[int, in
     return n
 
 
+def roi_fwd_kernel_name(B: int, H: int, W: int, Cc: int, R: int, crop: Sequence[int], pool: int,
+                        want_winner: bool = False) -> str:
+    """Name of the kernel frcnn_roi_crop_pool_fwd_ws launches for a channels-last, aligned map
+    and a full workspace (frcnn_roi_fwd_plan)."""
+    band = lib.frcnn_roi_fwd_plan(B, H, W, Cc, R, int(crop[0]), int(crop[1]), pool, int(want_winner))
+    w = "true" if want_winner else "false"
+    return f"roi_fwd_band_kernel<{pool},{w}>" if band else f"roi_fwd_stage_kernel<{pool},{w}>"
+
+
 def nchw_to_nhwc(x: torch.Tensor) -> torch.Tensor:
     """[B,C,H,W] contiguous -> new [B,H,W,C] contiguous tensor (frcnn_nchw_to_nhwc)."""
     s = _cont(x, "x", torch.float32)
