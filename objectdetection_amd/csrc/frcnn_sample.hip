@@ -14,13 +14,19 @@ namespace frcnn {
 constexpr int SBLOCK_BIG = 1024;
 constexpr int SBLOCK_SWITCH = 16;
 constexpr int SMAX_BATCH = 1024;
+// mini-batches up to SMALL_BATCH use the small instance of the LDS block (8.4 KB instead of
+// 29.9 KB): a workgroup that small still fits on a compute unit whose LDS is all but taken by
+// the band-resident RoI kernel of another stream (154 KB of 160), so it does not keep that
+// kernel's workgroups off the unit for as long as it runs
+constexpr int SMALL_BATCH = 256;
 
+template <int SMAX>
 struct SampleShared {
-    unsigned long long sel[SMAX_BATCH];    // composites being selected / sorted
-    unsigned long long inv[SMAX_BATCH];    // (list position << 32 | slot), sorted by position
-    uint32_t slot_item[SMAX_BATCH];        // payload per slot (anchor id / proposal id)
-    int32_t slot_gt[SMAX_BATCH];           // matched GT per slot
-    uint32_t order[SMAX_BATCH];            // final shuffle: order[r] = slot
+    unsigned long long sel[SMAX];          // composites being selected / sorted
+    unsigned long long inv[SMAX];          // (list position << 32 | slot), sorted by position
+    uint32_t slot_item[SMAX];              // payload per slot (anchor id / proposal id)
+    int32_t slot_gt[SMAX];                 // matched GT per slot
+    uint32_t order[SMAX];                  // final shuffle: order[r] = slot
     uint32_t hist[256];
     uint32_t sh[4];
     uint32_t wcnt[3 * (SBLOCK_BIG / 64)];
@@ -29,8 +35,8 @@ struct SampleShared {
 };
 
 // smallest `m` of key(0..M-1) by (key, position) -> s.sel[0..m) sorted ascending.
-template <int SBLOCK, typename KeyFn>
-__device__ void select_sorted(SampleShared& s, KeyFn key, int M, int m) {
+template <int SBLOCK, typename Shared, typename KeyFn>
+__device__ void select_sorted(Shared& s, KeyFn key, int M, int m) {
     if (m <= 0) return;                    // block-uniform
     uint32_t T;
     int less;
@@ -60,8 +66,8 @@ __device__ __forceinline__ int find_slot(const unsigned long long* inv, int lo, 
 // tf.where over the valid-anchor sub-list, module/data.py:108-110) else i.
 // On return (all threads): s.slot_item/slot_gt hold [positives | negatives] in
 // shuffled order, s.order the final permutation, s.tot = {P, Nneg, nop, status}.
-template <int SBLOCK, bool NEG_RANK, typename FlagFn, typename GtFn>
-__device__ void sample_two_lists(SampleShared& s, FlagFn flag, GtFn pos_gt, int M, int neg_gt,
+template <int SBLOCK, bool NEG_RANK, typename Shared, typename FlagFn, typename GtFn>
+__device__ void sample_two_lists(Shared& s, FlagFn flag, GtFn pos_gt, int M, int neg_gt,
                                  const uint32_t* kp, const uint32_t* kn, const uint32_t* ka,
                                  uint64_t seed, uint32_t image, uint32_t stream_base, int batch,
                                  int max_pos) {
@@ -180,7 +186,7 @@ __device__ void sample_two_lists(SampleShared& s, FlagFn flag, GtFn pos_gt, int 
 }
 
 // ---------------------------------------------------------------- RPN sampler ----
-template <int SBLOCK>
+template <int SBLOCK, int SMAX>
 __global__ void __launch_bounds__(SBLOCK)
 rpn_sample_kernel(const float4* __restrict__ anchors, int N, int W, int A,
                   const float4* __restrict__ gt, int G, const int32_t* __restrict__ best_gt,
@@ -191,7 +197,7 @@ rpn_sample_kernel(const float4* __restrict__ anchors, int N, int W, int A,
                   float4* __restrict__ batch_gt, long long* __restrict__ gt_list,
                   long long* __restrict__ batch_pos, float4* __restrict__ batch_reg_gt,
                   int32_t* __restrict__ counts) {
-    __shared__ SampleShared s;
+    __shared__ SampleShared<SMAX> s;
     const int b = blockIdx.x;
     const uint8_t* fl = flags + (size_t)b * N;
     const int32_t* bg = best_gt + (size_t)b * N;
@@ -236,14 +242,14 @@ rpn_sample_kernel(const float4* __restrict__ anchors, int N, int W, int A,
 }
 
 // --------------------------------------------------------------- head sampler ----
-template <int SBLOCK>
+template <int SBLOCK, int SMAX>
 __global__ void __launch_bounds__(SBLOCK)
 sample_proposals_kernel(const long long* __restrict__ p_label, int R, int bg_label,
                         const uint32_t* __restrict__ keys_pos, const uint32_t* __restrict__ keys_neg,
                         const uint32_t* __restrict__ keys_all, uint64_t seed, int image_base,
                         int batch, int max_pos, long long* __restrict__ tindex,
                         int32_t* __restrict__ counts) {
-    __shared__ SampleShared s;
+    __shared__ SampleShared<SMAX> s;
     const int b = blockIdx.x;
     const long long* pl = p_label + (size_t)b * R;
     auto flag = [&](int i) -> uint32_t { return pl[i] != (long long)bg_label ? 1u : 2u; };
@@ -340,15 +346,20 @@ extern "C" int frcnn_rpn_sample(const float* anchors, int H, int W, int A, const
     if (any && !all) return FRCNN_E_BADARG;
     const long long N = (long long)H * W * A;
     if (N > (1ll << 24) || batch > SMAX_BATCH) return FRCNN_E_UNSUPPORTED;
-#define FRCNN_RPN_SAMPLE(BLK)                                                                    \
-    FRCNN_LAUNCH(rpn_sample_kernel<BLK>, dim3(B), dim3(BLK), 0, (hipStream_t)stream,             \
+#define FRCNN_RPN_SAMPLE(BLK, SMX)                                                                    \
+    FRCNN_LAUNCH((rpn_sample_kernel<BLK, SMX>), dim3(B), dim3(BLK), 0, (hipStream_t)stream,             \
                  reinterpret_cast<const float4*>(anchors), (int)N, W, A,                         \
                  reinterpret_cast<const float4*>(gt), G, best_gt, flags, keys_pos, keys_neg,     \
                  keys_all, seed, image_base, batch, max_pos, batch_label,                        \
                  reinterpret_cast<float4*>(batch_anchor), reinterpret_cast<float4*>(batch_gt),   \
                  reinterpret_cast<long long*>(gt_list), reinterpret_cast<long long*>(batch_pos), \
                  reinterpret_cast<float4*>(batch_reg_gt), counts)
-    if (B < SBLOCK_SWITCH) FRCNN_RPN_SAMPLE(SBLOCK_BIG); else FRCNN_RPN_SAMPLE(FRCNN_TARGET_BLOCK);
+    if (B < SBLOCK_SWITCH) {
+        if (batch <= SMALL_BATCH) FRCNN_RPN_SAMPLE(SBLOCK_BIG, SMALL_BATCH); else FRCNN_RPN_SAMPLE(SBLOCK_BIG, SMAX_BATCH);
+    } else {
+        if (batch <= SMALL_BATCH) FRCNN_RPN_SAMPLE(FRCNN_TARGET_BLOCK, SMALL_BATCH);
+        else FRCNN_RPN_SAMPLE(FRCNN_TARGET_BLOCK, SMAX_BATCH);
+    }
 #undef FRCNN_RPN_SAMPLE
     return FRCNN_OK;
 }
@@ -365,12 +376,17 @@ extern "C" int frcnn_sample_proposals(const int64_t* p_label, int B, int R, int 
     const bool all = keys_pos && keys_neg && keys_all;
     if (any && !all) return FRCNN_E_BADARG;
     if (R > (1 << 24) || batch > SMAX_BATCH) return FRCNN_E_UNSUPPORTED;
-#define FRCNN_HEAD_SAMPLE(BLK)                                                                   \
-    FRCNN_LAUNCH(sample_proposals_kernel<BLK>, dim3(B), dim3(BLK), 0, (hipStream_t)stream,       \
+#define FRCNN_HEAD_SAMPLE(BLK, SMX)                                                                   \
+    FRCNN_LAUNCH((sample_proposals_kernel<BLK, SMX>), dim3(B), dim3(BLK), 0, (hipStream_t)stream,       \
                  reinterpret_cast<const long long*>(p_label), R, bg_label, keys_pos, keys_neg,   \
                  keys_all, seed, image_base, batch, max_pos,                                     \
                  reinterpret_cast<long long*>(tindex), counts)
-    if (B < SBLOCK_SWITCH) FRCNN_HEAD_SAMPLE(SBLOCK_BIG); else FRCNN_HEAD_SAMPLE(FRCNN_TARGET_BLOCK);
+    if (B < SBLOCK_SWITCH) {
+        if (batch <= SMALL_BATCH) FRCNN_HEAD_SAMPLE(SBLOCK_BIG, SMALL_BATCH); else FRCNN_HEAD_SAMPLE(SBLOCK_BIG, SMAX_BATCH);
+    } else {
+        if (batch <= SMALL_BATCH) FRCNN_HEAD_SAMPLE(FRCNN_TARGET_BLOCK, SMALL_BATCH);
+        else FRCNN_HEAD_SAMPLE(FRCNN_TARGET_BLOCK, SMAX_BATCH);
+    }
 #undef FRCNN_HEAD_SAMPLE
     return FRCNN_OK;
 }
