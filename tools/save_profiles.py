@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """Copy the judged summaries of a tools/collect_profiles.sh run from gpurun_out/<tag>/ into
-profiles/ (tracked) and derive profiles/roi_fwd_traffic.json (HBM bytes per launch of the
-dominant kernel: 2 x FETCH_SIZE (gfx950 reports half of a wide coalesced read) + WRITE_SIZE)."""
+profiles/ (tracked) and derive the dominant kernel's record in profiles/roi_fwd_traffic.json (HBM bytes per launch: 2 x FETCH_SIZE (gfx950 reports half of a wide coalesced read) + WRITE_SIZE)."""
 import csv
 import glob
 import json
@@ -32,12 +31,19 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             per[r["Dispatch_Id"]] = per.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
     vals[c] = sum(per.values()) / len(per)
 bench = json.load(open(os.path.join(src, "bench.json")))
+kernel = bench["roofline"]["kernel"]
 rec = {
     "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py workload, {tag}",
-    "batch": bench["config"]["images_per_gpu_per_step"], "channels": 512,
     "fetch_size_kb": vals["FETCH_SIZE"], "write_size_kb": vals["WRITE_SIZE"],
     "hbm_bytes_per_launch": 2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024,
     "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
 }
-json.dump(rec, open(os.path.join(dst, "roi_fwd_traffic.json"), "w"), indent=1)
+path = os.path.join(dst, "roi_fwd_traffic.json")
+doc = json.load(open(path)) if os.path.exists(path) else {}
+doc.update(batch=bench["config"]["images_per_gpu_per_step"], channels=512, config="600x1000")
+old = doc.setdefault("kernels", {}).get(kernel, {})
+if "co_bounds" in old:
+    rec["co_bounds"] = old["co_bounds"]            # hand-written floors stay with the kernel
+doc["kernels"][kernel] = rec
+json.dump(doc, open(path, "w"), indent=1)
 print(json.dumps(rec))
