@@ -314,6 +314,10 @@ roi_fwd_band_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
     const bool live0 = 2 * q < cw, live1 = 2 * q + 1 < cw;      // this lane's two sample columns
     const RoiDesc* dimg = desc + (size_t)b * R;
     const size_t bin_stride = (size_t)C;                         // floats between output columns
+    // output addressing: a lane's offset inside an output row is fixed for the whole launch, the
+    // row offset is uniform -- one 64-bit add per stored row, no per-row multiplies
+    const size_t lane_out = (size_t)(POOL == 1 ? 2 * q : q) * bin_stride + (size_t)g * BD_CG + quad * 4;
+    const size_t row_out = (size_t)PW * bin_stride;              // floats between output rows
     // byte address of the band inside the LDS (what a ds_read takes)
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)band_lds;
     const uint32_t lds_adj = lds_base + (uint32_t)quad * 16u - (uint32_t)r0 * rowpitch;
@@ -394,9 +398,9 @@ roi_fwd_band_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
             const uint64_t xout0 = __ballot(live0 && !ok0), xout1 = __ballot(live1 && !ok1);
             const uint32_t a0 = xlo0 * BD_CELL + lds_adj, a1 = xhi0 * BD_CELL + lds_adj;
             const uint32_t a2 = xlo1 * BD_CELL + lds_adj, a3 = xhi1 * BD_CELL + lds_adj;
-            float* oroi = out + ((size_t)b * R + r) * (size_t)(PH * PW) * C + (size_t)g * BD_CG + quad * 4;
-            uint8_t* wroi = WIN ? winner + ((size_t)b * R + r) * (size_t)(PH * PW) * C +
-                                      (size_t)g * BD_CG + quad * 4 : nullptr;
+            const size_t roi_out = ((size_t)b * R + r) * (size_t)(PH * PW) * C;        // uniform
+            float* oroi = out + roi_out + lane_out;
+            uint8_t* wroi = WIN ? winner + roi_out + lane_out : nullptr;
             RowSet sA, sB;
             // no initial value: the first sample row of a walk reads both of its rows
             asm volatile("" : "=v"(sA.h0.a), "=v"(sA.h0.b), "=v"(sA.h1.a), "=v"(sA.h1.b),
@@ -407,7 +411,7 @@ roi_fwd_band_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
             // one sample row's two samples folded into the running maximum / stored
             auto fold = [&](int oy, int ky, Quad v0, Quad v1) {
                 if (POOL == 1) {
-                    float* o = oroi + ((size_t)oy * PW + 2 * q) * bin_stride;
+                    float* o = oroi + (size_t)oy * row_out;
                     if (live0) *reinterpret_cast<f32x4*>(o) = q_pack(v0);
                     if (live1) *reinterpret_cast<f32x4*>(o + bin_stride) = q_pack(v1);
                     return;
@@ -435,7 +439,7 @@ roi_fwd_band_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
                     best.b.x = vmax3(best.b.x, v0.b.x, v1.b.x); best.b.y = vmax3(best.b.y, v0.b.y, v1.b.y);
                 }
                 if (ky == POOL - 1 && q < PW) {
-                    const size_t o = ((size_t)oy * PW + q) * bin_stride;
+                    const size_t o = (size_t)oy * row_out;
                     *reinterpret_cast<f32x4*>(oroi + o) = q_pack(best);
                     if (WIN) *reinterpret_cast<uchar4*>(wroi + o) = arg;
                 }

@@ -22,16 +22,17 @@ with open(os.path.join(dst, f"{name}_pmc_roi_fwd.txt"), "w") as out:
         if os.path.isdir(d):
             out.write(subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"),
                                       d, "roi_fwd"], capture_output=True, text=True).stdout)
+bench = json.load(open(os.path.join(src, "bench.json")))
+kernel = bench["roofline"]["kernel"]
+kbase = kernel.split("<")[0]                   # the step's RoI kernel (others only run untimed)
 vals = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(os.path.join(src, f"pmc_{c}", "*", "*counter_collection.csv"))[0]
     per = {}
     for r in csv.DictReader(open(f)):
-        if "roi_fwd" in r["Kernel_Name"] and r["Counter_Name"] == c:
+        if kbase in r["Kernel_Name"] and r["Counter_Name"] == c:
             per[r["Dispatch_Id"]] = per.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
     vals[c] = sum(per.values()) / len(per)
-bench = json.load(open(os.path.join(src, "bench.json")))
-kernel = bench["roofline"]["kernel"]
 rec = {
     "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py workload, {tag}",
     "fetch_size_kb": vals["FETCH_SIZE"], "write_size_kb": vals["WRITE_SIZE"],
