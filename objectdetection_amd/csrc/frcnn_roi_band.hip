@@ -353,12 +353,12 @@ roi_fwd_band_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
     f32x4 stg[8];                                // cells of a feature row on their way to a row set
 #pragma unroll
     for (int i = 0; i < 8; ++i) stg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    uint4 piece[2], bw;
     int n_cur = claim();
-    fetch(n_cur, piece, bw);
 #pragma unroll 1
     while (n_cur < R) {
         {
+            uint4 piece[2], bw;
+            fetch(n_cur, piece, bw);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
                 *reinterpret_cast<uint4*>(ring + (sel + 4 * t) * BD_ENTRY + part * 16) = piece[t];
@@ -369,7 +369,6 @@ roi_fwd_band_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
                     make_uint4((uint32_t)(n_cur + lane), mine, mine_direct, 0u);
         }
         const int n_next = claim();
-        fetch(n_next, piece, bw);
         n_cur = n_next;
         {
             // header and descriptor words of ring entry vi are read while entry vi - 1 is processed
