@@ -371,24 +371,14 @@ roi_fwd_band_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
         const int n_next = claim();
         n_cur = n_next;
         {
-            // header and descriptor words of ring entry vi are read while entry vi - 1 is processed
-            uint4 hv_n = *reinterpret_cast<const uint4*>(hdr);
-            uint32_t ydv_n = *reinterpret_cast<const uint32_t*>(ring + (lane & 31) * 4);
-            uint4 xdv_n = *reinterpret_cast<const uint4*>(ring + 128 + q * 16);
 #pragma unroll 1
             for (int vi = 0; vi < BD_RING; ++vi) {
-            const uint4 hv = hv_n;
-            uint32_t ydv = ydv_n;
-            const uint4 xdv = xdv_n;
-            {
-                const int vn = (vi + 1) & (BD_RING - 1);
-                hv_n = *reinterpret_cast<const uint4*>(hdr + vn * BD_HDR);
-                ydv_n = *reinterpret_cast<const uint32_t*>(ring + vn * BD_ENTRY + (lane & 31) * 4);
-                xdv_n = *reinterpret_cast<const uint4*>(ring + vn * BD_ENTRY + 128 + q * 16);
-            }
+            const uint4 hv = *reinterpret_cast<const uint4*>(hdr + vi * BD_HDR);
             const int r = (int)bd_first(hv.x);
             const uint32_t rows = bd_first(hv.y), rows_direct = bd_first(hv.z);
             if ((rows | rows_direct) == 0u) continue;                               // uniform
+            uint32_t ydv = *reinterpret_cast<const uint32_t*>(ring + vi * BD_ENTRY + (lane & 31) * 4);
+            const uint4 xdv = *reinterpret_cast<const uint4*>(ring + vi * BD_ENTRY + 128 + q * 16);
             const uint32_t xlo0 = xdv.x & 0xFFFu, xhi0 = (xdv.x >> 12) & 0xFFFu;
             const uint32_t xlo1 = xdv.z & 0xFFFu, xhi1 = (xdv.z >> 12) & 0xFFFu;
             const bool ok0 = live0 && ((xdv.x >> 24) & 1u), ok1 = live1 && ((xdv.z >> 24) & 1u);
