@@ -169,7 +169,7 @@ __device__ __forceinline__ uint32_t band_match(uint4 w, uint32_t want) {
 // are branches inside one statement whose set operands are tied ("+v"), so the compiler sees
 // straight-line code and cannot answer the conditional writes with register copies (it did:
 // about twenty v_mov_b64 per sample row in every C++ formulation of this step).
-// v[96:111] and v[112:127] are the staging registers of the four 16-byte LDS reads of the
+// v[64:79] and v[80:95] are the staging registers of the four 16-byte LDS reads of the
 // ceil and the floor feature row.
 // Dependent packed instructions are kept one instruction apart (gfx940-family forwarding
 // hazard of instructions that write through op_sel / packed destinations).
@@ -183,8 +183,8 @@ __device__ __forceinline__ uint32_t band_match(uint4 w, uint32_t want) {
     "ds_read_b128 v[" R1 "], v" R1A "\n"                                                     \
     "ds_read_b128 v[" R2 "], v" R2A "\n"                                                     \
     "ds_read_b128 v[" R3 "], v" R3A "\n"
-#define BD_ISSUE_LO(OFF) BD_ISSUE(OFF, "112:115", "116:119", "120:123", "124:127", "112", "116", "120", "124")
-#define BD_ISSUE_HI(OFF) BD_ISSUE(OFF, "96:99", "100:103", "104:107", "108:111", "96", "100", "104", "108")
+#define BD_ISSUE_LO(OFF) BD_ISSUE(OFF, "80:83", "84:87", "88:91", "92:95", "80", "84", "88", "92")
+#define BD_ISSUE_HI(OFF) BD_ISSUE(OFF, "64:67", "68:71", "72:75", "76:79", "64", "68", "72", "76")
 // set S <- the x-lerp of a staged row: four independent chains, dependent instructions four apart
 #define BD_XLERP(S, C0L, C0H, C1L, C1H, C2L, C2H, C3L, C3H)                                  \
     "v_pk_add_f32 v[" C1L "], v[" C1L "], v[" C0L "] neg_lo:[0,1] neg_hi:[0,1]\n"            \
@@ -199,8 +199,8 @@ __device__ __forceinline__ uint32_t band_match(uint4 w, uint32_t want) {
     "v_pk_add_f32 %[" S "1], v[" C0H "], v[" C1H "]\n"                                       \
     "v_pk_add_f32 %[" S "2], v[" C2L "], v[" C3L "]\n"                                       \
     "v_pk_add_f32 %[" S "3], v[" C2H "], v[" C3H "]\n"
-#define BD_XLERP_LO(S) BD_XLERP(S, "112:113", "114:115", "116:117", "118:119", "120:121", "122:123", "124:125", "126:127")
-#define BD_XLERP_HI(S) BD_XLERP(S, "96:97", "98:99", "100:101", "102:103", "104:105", "106:107", "108:109", "110:111")
+#define BD_XLERP_LO(S) BD_XLERP(S, "80:81", "82:83", "84:85", "86:87", "88:89", "90:91", "92:93", "94:95")
+#define BD_XLERP_HI(S) BD_XLERP(S, "64:65", "66:67", "68:69", "70:71", "72:73", "74:75", "76:77", "78:79")
 // v = L + (H - L) * fy for the four pairs
 #define BD_YLERP(L, H)                                                                       \
     "v_pk_add_f32 %[v0a], %[" H "0], %[" L "0] neg_lo:[0,1] neg_hi:[0,1]\n"                        \
@@ -220,7 +220,7 @@ __device__ __forceinline__ uint32_t band_match(uint4 w, uint32_t want) {
 // The reads of a sample row are issued one row ahead (BD_ISSUE_NEXT, from the NEXT row's word
 // %[ywn] and row offsets) right after the staged cells of the current row have been consumed,
 // so their latency passes behind the current row's y-lerp, its pooling and the next row's
-// scalar decode.  The staging registers are operands pinned to v[96:127]: they stay live from
+// scalar decode.  The staging registers are operands pinned to v[64:95]: they stay live from
 // one statement to the next.
 #define BD_ISSUE_NEXT(TAG)                                                                   \
     "s_bitcmp1_b32 %[ywn], 27\n"                                                             \
@@ -251,8 +251,8 @@ __device__ __forceinline__ uint32_t band_match(uint4 w, uint32_t want) {
     "s_cbranch_scc0 .Lbd_zero_%=\n"                                                          \
     BD_YLERP(SETLO, SETHI)
 #define BD_STAGING(c)                                                                        \
-    "+{v[96:99]}"(c[0]), "+{v[100:103]}"(c[1]), "+{v[104:107]}"(c[2]), "+{v[108:111]}"(c[3]),  \
-    "+{v[112:115]}"(c[4]), "+{v[116:119]}"(c[5]), "+{v[120:123]}"(c[6]), "+{v[124:127]}"(c[7])
+    "+{v[64:67]}"(c[0]), "+{v[68:71]}"(c[1]), "+{v[72:75]}"(c[2]), "+{v[76:79]}"(c[3]),  \
+    "+{v[80:83]}"(c[4]), "+{v[84:87]}"(c[5]), "+{v[88:91]}"(c[6]), "+{v[92:95]}"(c[7])
 
 // The lerped feature rows a wave holds: two register sets, feature row r lives in set r & 1.
 // A sample row's floor and ceil rows are neighbours, so they never compete for a set, and a
@@ -261,7 +261,7 @@ __device__ __forceinline__ uint32_t band_match(uint4 w, uint32_t want) {
 struct RowSet { Quad h0, h1; };
 
 template <int POOL, bool WIN>
-__global__ void __launch_bounds__(64 * BD_WAVES)
+__global__ void __launch_bounds__(64 * BD_WAVES) __attribute__((amdgpu_waves_per_eu(5, 5)))
 roi_fwd_band_kernel(const float* __restrict__ fmap, int H, int W, int C, long long sb, long long sh,
                     long long sw, const RoiDesc* __restrict__ desc, int R, int ch, int cw,
                     int ngroup, int nband, int nimg, int S, int T, float* __restrict__ out,
@@ -593,7 +593,7 @@ extern "C" size_t frcnn_roi_fwd_workspace_bytes(int B, int R) {
 // Which forward kernel a channels-last call is given (alignment and workspace aside).
 // The band kernel wins once its workgroups (B * C/32 * bands, one per CU at a time) fill the
 // chip about three times over: on the 600x1000 workload (C = 512, R = 2000, 3 bands) it takes
-// 0.98 / 1.79 / 3.38 ms at B = 16 / 32 / 64 against 1.02 / 1.94 / 3.92 ms for the per-RoI
+// 0.66 / 1.79 / 3.38 ms at B = 16 / 32 / 64 against 1.02 / 1.94 / 3.92 ms for the per-RoI
 // kernel, and loses below (0.56 vs 0.52 ms at B = 8).  A band is loaded once per workgroup
 // whatever R is: below about a thousand RoIs per image the per-RoI kernel is the faster one.
 // FRCNN_ROI_BAND_MIN_WG = n replaces the first threshold and lifts the second (n < 0: never).
