@@ -209,6 +209,22 @@ int frcnn_roi_crop_pool_fwd_ws(const float* fmap, int B, int H, int W, int C,
                                float* out, uint8_t* winner, void* workspace,
                                size_t workspace_bytes, frcnn_stream_t stream);
 
+/* The two halves of frcnn_roi_crop_pool_fwd_ws for callers that know the RoIs before the
+ * feature map is due (module/model.py:51 produces them, :53-55 consumes them): frcnn_roi_fwd_prepare
+ * writes the per-RoI sample geometry into the workspace if a channels-last call of these
+ * dimensions would run the band kernel (returns 1; 0: nothing to prepare; < 0: error), e.g. on the
+ * stream that computed the proposals; frcnn_roi_crop_pool_fwd_prepared is frcnn_roi_crop_pool_fwd_ws
+ * without that step (same arguments, same rois, ordered after the prepare call by the caller).
+ * A planar map is transposed by the second call as before. */
+int frcnn_roi_fwd_prepare(const float* rois, int B, int H, int W, int C, int R, int crop_h,
+                          int crop_w, int pool, int want_winner, void* workspace,
+                          size_t workspace_bytes, frcnn_stream_t stream);
+int frcnn_roi_crop_pool_fwd_prepared(const float* fmap, int B, int H, int W, int C,
+                                     int64_t sb, int64_t sh, int64_t sw, int64_t sc,
+                                     const float* rois, int R, int crop_h, int crop_w, int pool,
+                                     float* out, uint8_t* winner, void* workspace,
+                                     size_t workspace_bytes, frcnn_stream_t stream);
+
 /* [B,C,H,W] contiguous -> [B,H,W,C] contiguous (dst != src), tiled through LDS: the layout
  * change in front of the channels-last RoI kernels for callers whose backbone emits planar
  * maps (the reference's maps are channels-last already, module/model.py:12-17). */

@@ -59,6 +59,9 @@ _SIGS = {
     "frcnn_roi_fwd_plan": (_i, [_i] * 9),
     "frcnn_roi_crop_pool_fwd_ws": (_i, [_p, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _p, _i, _i, _i,
                                         _i, _p, _p, _p, _sz, _p]),
+    "frcnn_roi_fwd_prepare": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
+    "frcnn_roi_crop_pool_fwd_prepared": (_i, [_p, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _p, _i,
+                                              _i, _i, _i, _p, _p, _p, _sz, _p]),
     "frcnn_nchw_to_nhwc": (_i, [_p, _i, _i, _i, _i, _p, _p]),
     "frcnn_roi_crop_pool_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
     "frcnn_label_proposals": (_i, [_p, _p, _p, _i, _i, _i, _f, _f, _i, _i, _p, _p, _p, _p, _p, _p,

@@ -626,11 +626,38 @@ extern "C" int frcnn_nchw_to_nhwc(const float* src, int B, int C, int H, int W, 
     return FRCNN_OK;
 }
 
-extern "C" int frcnn_roi_crop_pool_fwd_ws(const float* fmap, int B, int H, int W, int C, int64_t sb,
-                                          int64_t sh, int64_t sw, int64_t sc, const float* rois,
-                                          int R, int crop_h, int crop_w, int pool, float* out,
-                                          uint8_t* winner, void* workspace, size_t workspace_bytes,
-                                          frcnn_stream_t stream) {
+static int launch_band_prep(const float* rois, int B, int H, int W, int R, int crop_h, int crop_w,
+                            int pool, void* workspace, hipStream_t st) {
+    const BandPlan plan = band_plan(H, W, crop_h, pool);
+    const int n_roi = B * R;
+    FRCNN_LAUNCH(roi_band_prep_kernel, dim3((n_roi + 255) / 256), dim3(256), 0, st,
+                 reinterpret_cast<const float4*>(rois), n_roi, H, W, crop_h, crop_w, pool, plan.nb,
+                 plan.S, plan.T, reinterpret_cast<RoiDesc*>(workspace));
+    return FRCNN_OK;
+}
+
+static bool band_workspace_ok(const void* workspace, size_t workspace_bytes, int B, int R) {
+    return workspace && workspace_bytes >= frcnn_roi_fwd_workspace_bytes(B, R) &&
+           (reinterpret_cast<uintptr_t>(workspace) % 16) == 0;
+}
+
+extern "C" int frcnn_roi_fwd_prepare(const float* rois, int B, int H, int W, int C, int R, int crop_h,
+                                     int crop_w, int pool, int want_winner, void* workspace,
+                                     size_t workspace_bytes, frcnn_stream_t stream) {
+    if (!rois || B <= 0 || H <= 0 || W <= 0 || C <= 0 || R <= 0 || crop_h <= 0 || crop_w <= 0)
+        return FRCNN_E_BADARG;
+    if (!band_wanted(B, H, W, C, R, crop_h, crop_w, pool, want_winner != 0) ||
+        !band_workspace_ok(workspace, workspace_bytes, B, R))
+        return 0;
+    const int rc = launch_band_prep(rois, B, H, W, R, crop_h, crop_w, pool, workspace,
+                                    (hipStream_t)stream);
+    return rc == FRCNN_OK ? 1 : rc;
+}
+
+static int roi_fwd_ws_impl(const float* fmap, int B, int H, int W, int C, int64_t sb, int64_t sh,
+                           int64_t sw, int64_t sc, const float* rois, int R, int crop_h, int crop_w,
+                           int pool, float* out, uint8_t* winner, void* workspace,
+                           size_t workspace_bytes, frcnn_stream_t stream, bool prepared) {
     if (!fmap || !rois || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || R <= 0 ||
         crop_h <= 0 || crop_w <= 0)
         return FRCNN_E_BADARG;
@@ -647,9 +674,9 @@ extern "C" int frcnn_roi_crop_pool_fwd_ws(const float* fmap, int B, int H, int W
             float* copy = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + desc_bytes);
             const int rc = frcnn_nchw_to_nhwc(fmap, B, C, H, W, copy, stream);
             if (rc != FRCNN_OK) return rc;
-            return frcnn_roi_crop_pool_fwd_ws(copy, B, H, W, C, (int64_t)H * W * C, (int64_t)W * C, C,
-                                              1, rois, R, crop_h, crop_w, pool, out, winner,
-                                              workspace, desc_bytes, stream);
+            return roi_fwd_ws_impl(copy, B, H, W, C, (int64_t)H * W * C, (int64_t)W * C, C, 1, rois, R,
+                                   crop_h, crop_w, pool, out, winner, workspace, desc_bytes, stream,
+                                   prepared);
         }
     }
     const bool aligned = sc == 1 && (C % BD_CG) == 0 && (sb % 4) == 0 && (sh % 4) == 0 &&
@@ -660,17 +687,16 @@ extern "C" int frcnn_roi_crop_pool_fwd_ws(const float* fmap, int B, int H, int W
     const BandPlan plan = band_plan(H, W, crop_h, pool);
     const int ngroup = C / BD_CG;
     const bool band_path = aligned && band_wanted(B, H, W, C, R, crop_h, crop_w, pool, winner != nullptr) &&
-                           workspace && workspace_bytes >= frcnn_roi_fwd_workspace_bytes(B, R) &&
-                           (reinterpret_cast<uintptr_t>(workspace) % 16) == 0;
+                           band_workspace_ok(workspace, workspace_bytes, B, R);
     if (!band_path)
         return frcnn_roi_crop_pool_fwd(fmap, B, H, W, C, sb, sh, sw, sc, rois, R, crop_h, crop_w,
                                        pool, out, winner, stream);
     hipStream_t st = (hipStream_t)stream;
     RoiDesc* desc = reinterpret_cast<RoiDesc*>(workspace);
-    const int n_roi = B * R;
-    FRCNN_LAUNCH(roi_band_prep_kernel, dim3((n_roi + 255) / 256), dim3(256), 0, st,
-                 reinterpret_cast<const float4*>(rois), n_roi, H, W, crop_h, crop_w, pool, plan.nb,
-                 plan.S, plan.T, desc);
+    if (!prepared) {
+        const int rc = launch_band_prep(rois, B, H, W, R, crop_h, crop_w, pool, workspace, st);
+        if (rc != FRCNN_OK) return rc;
+    }
     const size_t lds = (size_t)plan.T * W * BD_CELL + BD_LDS_RING + 64;    // + the claim counter
     const dim3 grid((unsigned)((long long)ngroup * plan.nb * B)), block(64 * BD_WAVES);
 #define FRCNN_BAND(P, WN)                                                                          \
@@ -686,4 +712,23 @@ extern "C" int frcnn_roi_crop_pool_fwd_ws(const float* fmap, int B, int H, int W
     else           { FRCNN_BAND(1, false); }
 #undef FRCNN_BAND
     return FRCNN_OK;
+}
+
+extern "C" int frcnn_roi_crop_pool_fwd_ws(const float* fmap, int B, int H, int W, int C, int64_t sb,
+                                          int64_t sh, int64_t sw, int64_t sc, const float* rois,
+                                          int R, int crop_h, int crop_w, int pool, float* out,
+                                          uint8_t* winner, void* workspace, size_t workspace_bytes,
+                                          frcnn_stream_t stream) {
+    return roi_fwd_ws_impl(fmap, B, H, W, C, sb, sh, sw, sc, rois, R, crop_h, crop_w, pool, out,
+                           winner, workspace, workspace_bytes, stream, false);
+}
+
+extern "C" int frcnn_roi_crop_pool_fwd_prepared(const float* fmap, int B, int H, int W, int C,
+                                                int64_t sb, int64_t sh, int64_t sw, int64_t sc,
+                                                const float* rois, int R, int crop_h, int crop_w,
+                                                int pool, float* out, uint8_t* winner,
+                                                void* workspace, size_t workspace_bytes,
+                                                frcnn_stream_t stream) {
+    return roi_fwd_ws_impl(fmap, B, H, W, C, sb, sh, sw, sc, rois, R, crop_h, crop_w, pool, out,
+                           winner, workspace, workspace_bytes, stream, true);
 }

@@ -247,11 +247,12 @@ def nchw_to_nhwc(x: torch.Tensor) -> torch.Tensor:
 def roi_crop_pool_fwd(fmap: torch.Tensor, rois: torch.Tensor, crop: Tuple[int, int] = (14, 14),
                       pool: int = 2, want_winner: bool = False, out: Optional[torch.Tensor] = None,
                       workspace: Optional[torch.Tensor] = None,
-                      winner: Optional[torch.Tensor] = None):
+                      winner: Optional[torch.Tensor] = None, prepared: bool = False):
     """fmap [B,H,W,C] (any strides; channels-last is the fast layout), rois [B,R,4]
     -> pooled [B,R,crop_h/pool,crop_w/pool,C] (+ winner u8).  With `workspace` (a uint8 tensor
     of roi_fwd_workspace_bytes(B,R) bytes) the call goes through frcnn_roi_crop_pool_fwd_ws
-    (band-resident kernel when FRCNN_ROI_BAND_MIN_WG enables it, the same kernels otherwise)."""
+    (band-resident kernel for large calls, the same kernels otherwise); prepared=True after
+    roi_fwd_prepare() returned True for the same rois and workspace."""
     f = _dev(fmap, "fmap", torch.float32)
     if f.dim() != 4:
         raise ValueError("fmap must be [B,H,W,C]")
@@ -274,7 +275,8 @@ def roi_crop_pool_fwd(fmap: torch.Tensor, rois: torch.Tensor, crop: Tuple[int, i
     with torch.cuda.device(f.device):
         if workspace is not None:
             _dev(workspace, "workspace", torch.uint8)
-            check("frcnn_roi_crop_pool_fwd_ws", lib.frcnn_roi_crop_pool_fwd_ws(
+            fn = lib.frcnn_roi_crop_pool_fwd_prepared if prepared else lib.frcnn_roi_crop_pool_fwd_ws
+            check("frcnn_roi_crop_pool_fwd_ws", fn(
                 _ptr(f), B, H, W, Cc, sb, sh, sw, sc, _ptr(r), R, crop[0], crop[1], pool,
                 _ptr(out), _ptr(win), _ptr(workspace), workspace.numel(), _stream(f)))
         else:
@@ -282,6 +284,24 @@ def roi_crop_pool_fwd(fmap: torch.Tensor, rois: torch.Tensor, crop: Tuple[int, i
                 _ptr(f), B, H, W, Cc, sb, sh, sw, sc, _ptr(r), R, crop[0], crop[1], pool, _ptr(out),
                 _ptr(win), _stream(f)))
     return out, win
+
+
+def roi_fwd_prepare(rois: torch.Tensor, fmap_shape: Tuple[int, int, int, int],
+                    crop: Tuple[int, int], pool: int, want_winner: bool,
+                    workspace: torch.Tensor) -> bool:
+    """frcnn_roi_fwd_prepare on the current stream: True if the workspace now holds the sample
+    geometry of `rois` (pass prepared=True to roi_crop_pool_fwd), False if there was nothing to
+    prepare for a call of these dimensions."""
+    r = _cont(rois, "rois", torch.float32)
+    _dev(workspace, "workspace", torch.uint8)
+    B, H, W, Cc = fmap_shape
+    with torch.cuda.device(r.device):
+        rc = lib.frcnn_roi_fwd_prepare(_ptr(r), B, H, W, Cc, r.shape[1], crop[0], crop[1], pool,
+                                       int(want_winner), _ptr(workspace), workspace.numel(),
+                                       _stream(r))
+    if rc < 0:
+        check("frcnn_roi_fwd_prepare", rc)
+    return rc == 1
 
 
 def roi_crop_pool_bwd(dY: torch.Tensor, winner: Optional[torch.Tensor], rois: torch.Tensor,

@@ -69,8 +69,11 @@ class RegionProposalPath:
         # workspace of frcnn_roi_crop_pool_fwd_ws; fmap_planar: the caller's feature maps are
         # stored [B,C,H,W] (passed as the permuted [B,H,W,C] view) and are transposed into this
         # workspace before the channels-last RoI kernel runs
-        self.roi_ws = e((ops.roi_fwd_workspace_bytes(
-            B, R, (cfg.H, cfg.W, channels) if fmap_planar else None),), u8)
+        # One workspace per buffer set: the sample geometry of a batch's RoIs is written on the
+        # proposal stream right after the NMS (frcnn_roi_fwd_prepare), while the RoI kernel of the
+        # batch before may still be reading its own.
+        self.fmap_planar = fmap_planar
+        roi_ws_bytes = ops.roi_fwd_workspace_bytes(B, R, (cfg.H, cfg.W, channels) if fmap_planar else None)
         self.pooled = e((B, R, ph, pw, channels), f32) if alloc_pooled else None
         self.winner = e((B, R, ph, pw, channels), u8) if want_winner and alloc_pooled else None
         self._sets = []
@@ -79,6 +82,7 @@ class RegionProposalPath:
                      nms_ws=e((ops.nms_workspace_bytes(B, K, R),), u8),
                      topk_ws=e((ops.topk_sort_workspace_bytes(B, N) if topk == "sort" else 1,), u8),
                      proposed=e((B, R, 4), f32), keep_pos=e((B, R), i32), keep_count=e((B,), i32),
+                     roi_ws=e((roi_ws_bytes,), u8),
                      ev=[torch.cuda.Event() for _ in range(5)])
             if train:
                 S, S2 = cfg.rpn_batch, cfg.head_batch
@@ -211,7 +215,14 @@ class RegionProposalPath:
             _p(d["keep_pos"]), _p(d["keep_count"]), _p(d["nms_ws"]), d["nms_ws"].numel(), ps))
         if nms_events is not None:
             nms_events[1].record(prop)
-        ev[1].record(prop)                             # proposals ready
+        prepared = 0
+        if not skip_roi:
+            prepared = lib.frcnn_roi_fwd_prepare(
+                _p(d["proposed"]), B, cfg.H, cfg.W, self.C, cfg.post_n, cfg.crop[0], cfg.crop[1],
+                self.pool, int(self.winner is not None), _p(d["roi_ws"]), d["roi_ws"].numel(), ps)
+            if prepared < 0:
+                check("frcnn_roi_fwd_prepare", prepared)
+        ev[1].record(prop)                             # proposals (and their geometry) ready
         if self.depth == 2:
             main.wait_event(ev[1])
         if self.train:
@@ -229,10 +240,11 @@ class RegionProposalPath:
         if roi_events is not None:
             roi_events[0].record(main)
         if not skip_roi:
-            check("frcnn_roi_crop_pool_fwd_ws", lib.frcnn_roi_crop_pool_fwd_ws(
+            fwd = lib.frcnn_roi_crop_pool_fwd_prepared if prepared == 1 else lib.frcnn_roi_crop_pool_fwd_ws
+            check("frcnn_roi_crop_pool_fwd_ws", fwd(
                 _p(fmap), B, cfg.H, cfg.W, self.C, sb, sh, sw, sc, _p(d["proposed"]), cfg.post_n,
                 cfg.crop[0], cfg.crop[1], self.pool, _p(self.pooled), _p(self.winner),
-                _p(self.roi_ws), self.roi_ws.numel(), st))
+                _p(d["roi_ws"]), d["roi_ws"].numel(), st))
         if roi_events is not None:
             roi_events[1].record(main)
         if self.train:

@@ -61,13 +61,25 @@ class _Path:
         n = ops.roi_fwd_workspace_bytes(B, R, (H, W, C) if self.kind == "planar" else None)
         return torch.empty(n, dtype=torch.uint8, device=dev)
 
+    def forward(self, fm, rois, crop, pool, want_winner=False):
+        """fm [B,H,W,C] contiguous on the device -> (pooled, winner) through this path."""
+        from objectdetection_amd import ops
+        B, H, W, C = fm.shape
+        ws = self.ws(B, rois.shape[1], H, W, C, fm.device)
+        prepared = False
+        if self.kind == "band_prepared":
+            prepared = ops.roi_fwd_prepare(rois, (B, H, W, C), crop, pool, want_winner, ws)
+            assert prepared == (not (pool == 1 and want_winner))
+        return ops.roi_crop_pool_fwd(self.fmap(fm), rois, crop, pool, want_winner=want_winner,
+                                     workspace=ws, prepared=prepared)
 
-@pytest.fixture(params=["per_roi", "band", "planar"])
+
+@pytest.fixture(params=["per_roi", "band", "band_prepared", "planar"])
 def ws_for(request, monkeypatch):
     """The forward entry points: frcnn_roi_crop_pool_fwd (one wave per RoI and slice),
     frcnn_roi_crop_pool_fwd_ws with its band kernel forced on at test sizes, and the same entry
     point on a planar [B,C,H,W] map (transposed into the workspace, then the per-RoI kernel)."""
-    if request.param == "band":
+    if request.param in ("band", "band_prepared"):     # the two-call form: prepare, then run
         monkeypatch.setenv("FRCNN_ROI_BAND_MIN_WG", "1")
     return _Path(request.param)
 
@@ -85,9 +97,8 @@ def test_roi_forward_stress(dev, ws_for, C, H, W):
     rois[0, 1] = [np.nan, 0.1, 0.5, 0.6]
     rois[0, 2] = [0.2, 0.2, 0.2, 0.2]
     for pool, win in ((2, True), (2, False), (1, False)):
-        out, w = ops.roi_crop_pool_fwd(ws_for.fmap(torch.tensor(fm, device=dev)),
-                                       torch.tensor(rois, device=dev), (14, 14), pool,
-                                       want_winner=win, workspace=ws_for.ws(B, R, H, W, C, dev))
+        out, w = ws_for.forward(torch.tensor(fm, device=dev), torch.tensor(rois, device=dev),
+                                (14, 14), pool, want_winner=win)
         for b in range(B):
             ro, rw = c_oracle.roi_crop_pool(lib, fm[b], rois[b], (14, 14), pool, want_winner=win)
             got = out[b].cpu().numpy()
@@ -107,9 +118,7 @@ def test_roi_forward_other_crop_sizes(dev, ws_for):
     fm = rng.standard_normal((1, H, W, C)).astype(np.float32)
     rois = _boxes(rng, 300, H, W)[None]
     for crop, pool in (((16, 16), 2), ((12, 12), 1), ((7, 7), 1), ((14, 8), 2)):
-        out, _ = ops.roi_crop_pool_fwd(ws_for.fmap(torch.tensor(fm, device=dev)),
-                                       torch.tensor(rois, device=dev), crop, pool,
-                                       workspace=ws_for.ws(1, 300, H, W, C, dev))
+        out, _ = ws_for.forward(torch.tensor(fm, device=dev), torch.tensor(rois, device=dev), crop, pool)
         ro, _ = c_oracle.roi_crop_pool(lib, fm[0], rois[0], crop, pool, want_winner=False)
         got = out[0].cpu().numpy()
         assert ((got == ro) | (np.isnan(got) & np.isnan(ro))).all(), (crop, pool)
