@@ -208,7 +208,9 @@ def launcher_command(n, argv):
             os.path.abspath(__file__)] + list(argv)
 
 
-def timed_alone(fn, device, reps=5):
+def timed_alone(fn, device, reps=5, skip=1):
+    """Mean HIP-event time of fn() alone on the chip, the first `skip` calls left out (a long
+    kernel needs a few launches before the clocks settle after a quiet phase)."""
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ts = []
     for _ in range(reps):
@@ -217,7 +219,7 @@ def timed_alone(fn, device, reps=5):
         e1.record()
         torch.cuda.synchronize(device)
         ts.append(e0.elapsed_time(e1))
-    return float(np.mean(ts[1:]))
+    return float(np.mean(ts[skip:]))
 
 
 def kernel_table(path, cfg, B, C, fmap, score, coord, gt, label, device):
@@ -230,8 +232,8 @@ def kernel_table(path, cfg, B, C, fmap, score, coord, gt, label, device):
     a = path.anchor.reshape(-1, 4)
     rows = []
 
-    def add(name, fn, nbytes):
-        ms = timed_alone(fn, device)
+    def add(name, fn, nbytes, **kw):
+        ms = timed_alone(fn, device, **kw)
         rows.append(dict(name=name, ms_alone=ms, bytes=int(nbytes),
                          frac=nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS))
 
@@ -253,11 +255,11 @@ def kernel_table(path, cfg, B, C, fmap, score, coord, gt, label, device):
     add(ops.roi_fwd_kernel_name(B, cfg.H, cfg.W, C, R, cfg.crop, cfg.pool),
         lambda: ops.roi_crop_pool_fwd(fmap, path.proposed, cfg.crop, cfg.pool, out=path.pooled,
                                       workspace=path.roi_ws),
-        algorithmic_bytes_roi(cfg, C, B))
+        algorithmic_bytes_roi(cfg, C, B), reps=24, skip=8)
     if ops.roi_fwd_kernel_name(B, cfg.H, cfg.W, C, R, cfg.crop, cfg.pool).startswith("roi_fwd_band"):
         add("roi_fwd_stage_kernel<2,false> (per-RoI kernel, not in the step)",
             lambda: ops.roi_crop_pool_fwd(fmap, path.proposed, cfg.crop, cfg.pool, out=path.pooled),
-            algorithmic_bytes_roi(cfg, C, B))
+            algorithmic_bytes_roi(cfg, C, B), reps=24, skip=8)
     add("label_proposals_kernel", lambda: ops.label_proposals(path.proposed, gt, label, cfg.fg_thr,
                                                               cfg.iou_floor, cfg.bg_label,
                                                               cfg.num_classes),
@@ -397,7 +399,7 @@ def main():
         roi_alone_ms = timed_alone(lambda: ops.roi_crop_pool_fwd(fmap, path.proposed, cfg.crop,
                                                                  cfg.pool, out=path.pooled,
                                                                  workspace=path.roi_ws),
-                                   device, reps=6)
+                                   device, reps=24, skip=8)
         roi_kernel = ops.roi_fwd_kernel_name(B, cfg.H, cfg.W, C, cfg.post_n, cfg.crop, cfg.pool)
         kernels = kernel_table(path, cfg, B, C, fmap, score, coord, gt, label, device) \
             if not args.inference else None
