@@ -32,7 +32,9 @@ constexpr int BD_MAXCROP = 16;                 // samples per axis
 constexpr int BD_CG = 32;                      // channels per workgroup
 constexpr int BD_CELL = BD_CG * 4;             // bytes of one cell's channel group
 constexpr int BD_WAVES = 16;
-constexpr int BD_RING = 8;                     // descriptors a wave keeps in LDS at a time
+constexpr int BD_RING = 4;                     // descriptors a wave keeps in LDS at a time
+constexpr int BD_PIECES = BD_RING / 4;         // 16-byte descriptor pieces a lane moves per claim
+static_assert(BD_RING % 4 == 0, "a wave moves four descriptors (64 pieces) per instruction");
 constexpr int BD_ENTRY = 256;                  // bytes of a descriptor's y and x parts
 constexpr int BD_HDR = 16;                     // bytes of a ring header {roi, rows, rows_direct}
 constexpr int BD_LDS_TOTAL = 160 * 1024;
@@ -326,10 +328,13 @@ roi_fwd_band_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
     unsigned char* hdr = band_lds + (size_t)T * rowpitch + (size_t)BD_WAVES * BD_RING * BD_ENTRY +
                          (size_t)wave * BD_RING * BD_HDR;
 
-    // The waves of a workgroup claim the image's RoIs eight at a time from a counter in LDS (a
-    // fixed share per wave leaves the faster waves idle for a tenth of the workgroup's time).
-    // The descriptors of the next claim are fetched into registers before the current eight are
-    // processed, whether or not this band has rows of them: nothing waits on the fetch.
+    // The waves of a workgroup claim the image's RoIs BD_RING at a time from a counter in LDS (a
+    // fixed share per wave leaves the faster waves idle for a tenth of the workgroup's time) and
+    // copy the claimed descriptors into their ring, whether or not this band has rows of them.
+    // Fetching a claim ahead, or reading ring entries ahead of their visit, only cost registers:
+    // the other waves of the SIMD cover these latencies.  A small ring also leaves 23 KB of the
+    // CU's LDS to the workgroups of other kernels, which otherwise keep a band workgroup waiting
+    // for one contiguous 154 KB block.
     const int sel = lane >> 4, part = lane & 15;   // piece t of a lane: part `part` of entry sel + 4 t
     auto claim = [&]() -> int {
         uint32_t n = 0;
@@ -338,9 +343,9 @@ roi_fwd_band_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
         return (int)bd_first(n);
     };
-    auto fetch = [&](int n, uint4 (&piece)[2], uint4& bw) {
+    auto fetch = [&](int n, uint4 (&piece)[BD_PIECES], uint4& bw) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < BD_PIECES; ++t) {
             const int rr = n + sel + 4 * t;
             piece[t] = make_uint4(0u, 0u, 0u, 0u);
             if (rr < R)
@@ -357,10 +362,10 @@ roi_fwd_band_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
 #pragma unroll 1
     while (n_cur < R) {
         {
-            uint4 piece[2], bw;
+            uint4 piece[BD_PIECES], bw;
             fetch(n_cur, piece, bw);
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < BD_PIECES; ++t)
                 *reinterpret_cast<uint4*>(ring + (sel + 4 * t) * BD_ENTRY + part * 16) = piece[t];
             const uint32_t mine = band_match(bw, (uint32_t)k);
             const uint32_t mine_direct = k == 0 ? band_match(bw, BD_DIRECT) : 0u;

@@ -13,6 +13,7 @@ namespace frcnn {
 // SBLOCK_SWITCH images, FRCNN_TARGET_BLOCK from there on
 constexpr int SBLOCK_BIG = 1024;
 constexpr int SBLOCK_SWITCH = 16;
+constexpr int SBLOCK_MID = 256;                // one wave per SIMD: still fits beside a RoI workgroup
 constexpr int SMAX_BATCH = 1024;
 // mini-batches up to SMALL_BATCH use the small instance of the LDS block (8.4 KB instead of
 // 29.9 KB): a workgroup that small still fits on a compute unit whose LDS is all but taken by
@@ -357,8 +358,8 @@ extern "C" int frcnn_rpn_sample(const float* anchors, int H, int W, int A, const
     if (B < SBLOCK_SWITCH) {
         if (batch <= SMALL_BATCH) FRCNN_RPN_SAMPLE(SBLOCK_BIG, SMALL_BATCH); else FRCNN_RPN_SAMPLE(SBLOCK_BIG, SMAX_BATCH);
     } else {
-        if (batch <= SMALL_BATCH) FRCNN_RPN_SAMPLE(FRCNN_TARGET_BLOCK, SMALL_BATCH);
-        else FRCNN_RPN_SAMPLE(FRCNN_TARGET_BLOCK, SMAX_BATCH);
+        if (batch <= SMALL_BATCH) FRCNN_RPN_SAMPLE(SBLOCK_MID, SMALL_BATCH);
+        else FRCNN_RPN_SAMPLE(SBLOCK_MID, SMAX_BATCH);
     }
 #undef FRCNN_RPN_SAMPLE
     return FRCNN_OK;
@@ -384,8 +385,8 @@ extern "C" int frcnn_sample_proposals(const int64_t* p_label, int B, int R, int 
     if (B < SBLOCK_SWITCH) {
         if (batch <= SMALL_BATCH) FRCNN_HEAD_SAMPLE(SBLOCK_BIG, SMALL_BATCH); else FRCNN_HEAD_SAMPLE(SBLOCK_BIG, SMAX_BATCH);
     } else {
-        if (batch <= SMALL_BATCH) FRCNN_HEAD_SAMPLE(FRCNN_TARGET_BLOCK, SMALL_BATCH);
-        else FRCNN_HEAD_SAMPLE(FRCNN_TARGET_BLOCK, SMAX_BATCH);
+        if (batch <= SMALL_BATCH) FRCNN_HEAD_SAMPLE(SBLOCK_MID, SMALL_BATCH);
+        else FRCNN_HEAD_SAMPLE(SBLOCK_MID, SMAX_BATCH);
     }
 #undef FRCNN_HEAD_SAMPLE
     return FRCNN_OK;

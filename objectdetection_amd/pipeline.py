@@ -56,6 +56,9 @@ class RegionProposalPath:
         self.train, self.fuse_pool, self.depth = train, fuse_pool, depth
         self.side = torch.cuda.Stream(self.device) if train else None
         self.prop_stream = torch.cuda.Stream(self.device) if depth == 2 else None
+        # the RoI geometry (frcnn_roi_fwd_prepare) is computed beside both chains: behind the NMS,
+        # but neither in front of the next batch's top-k nor in front of the RoI kernel
+        self.prep_stream = torch.cuda.Stream(self.device) if depth == 2 else None
         self._calls = 0
         dev, B, N = self.device, batch, cfg.N
         f32, i32, i64, u8 = torch.float32, torch.int32, torch.int64, torch.uint8
@@ -215,16 +218,24 @@ class RegionProposalPath:
             _p(d["keep_pos"]), _p(d["keep_count"]), _p(d["nms_ws"]), d["nms_ws"].numel(), ps))
         if nms_events is not None:
             nms_events[1].record(prop)
+        ev[1].record(prop)                             # proposals ready
         prepared = 0
         if not skip_roi:
+            prep = self.prep_stream if self.depth == 2 else main
+            if self.depth == 2:
+                prep.wait_event(ev[1])
             prepared = lib.frcnn_roi_fwd_prepare(
                 _p(d["proposed"]), B, cfg.H, cfg.W, self.C, cfg.post_n, cfg.crop[0], cfg.crop[1],
-                self.pool, int(self.winner is not None), _p(d["roi_ws"]), d["roi_ws"].numel(), ps)
+                self.pool, int(self.winner is not None), _p(d["roi_ws"]), d["roi_ws"].numel(),
+                prep.cuda_stream)
             if prepared < 0:
                 check("frcnn_roi_fwd_prepare", prepared)
-        ev[1].record(prop)                             # proposals (and their geometry) ready
+            if self.depth == 2:
+                ev[3].record(prep)
         if self.depth == 2:
             main.wait_event(ev[1])
+            if not skip_roi:
+                main.wait_event(ev[3])
         if self.train:
             self.side.wait_event(ev[1])
             ss = self.side.cuda_stream
