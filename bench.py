@@ -243,8 +243,10 @@ def kernel_table(path, cfg, B, C, fmap, score, coord, gt, label, device):
                                                     seed=1, batch=cfg.rpn_batch,
                                                     max_pos=cfg.rpn_max_pos),
         B * (N * 5 + cfg.rpn_batch * 100))
+    sort_ws = path.topk_ws if path.topk == "sort" else torch.empty(
+        ops.topk_sort_workspace_bytes(B, N), dtype=torch.uint8, device=device)
     add("topk_sort (ts_* kernels)", lambda: ops.topk(score.reshape(B, -1), K, a, coord, "sort",
-                                                     workspace=path.topk_ws),
+                                                     workspace=sort_ws),
         B * (N * 4 + K * 16 + K * 8 + K * 16))
     if K <= 16384:
         add("topk_kernel (LDS radix select)",
