@@ -1,12 +1,12 @@
 // Fused bilinear RoI crop + max-pool, forward, "band-resident" formulation for batches.
 //
-// What limits a per-RoI kernel on this chip is the vector-memory path of a CU (64 B/clk): a
-// RoI's samples touch several times more feature bytes than the RoI produces, and every wave
-// fetches them again.  Here the feature map enters a CU once: a workgroup owns (image,
-// 32-channel group, band of feature rows), copies its band into LDS (up to 160 KB) and then
-// serves EVERY RoI of the image from there; its 16 waves take the RoIs round-robin.  The only
-// vector-memory traffic left is the pooled output (128 B per bin and group) and a 272-byte
-// descriptor per RoI and workgroup.
+// A per-RoI kernel fetches a RoI's feature cells again for every RoI and channel slice (several
+// times more bytes than the RoI produces, through a vector-memory path of 64 B/clk per CU) and
+// pays the box geometry per wave.  Here the feature map enters a CU once: a workgroup owns
+// (image, 32-channel group, band of feature rows), copies its band into LDS (119 KB for a
+// 37x62 map) and then serves EVERY RoI of the image from there.  The only vector-memory traffic
+// left is the pooled output (128 B per bin and group) and a 272-byte descriptor per RoI and
+// workgroup; measured HBM traffic is 1.015x the algorithmic bytes.
 //
 // Bands overlap by the largest number of rows an output row of an in-image box can span, so
 // every output row lies wholly inside one band; that band's workgroup produces it.  Output rows
@@ -15,10 +15,22 @@
 //
 // The per-RoI geometry (tf.image.crop_and_resize's sample coordinates, module/model.py:54) is
 // computed once per RoI by a small kernel into the descriptor: per sample row the two feature
-// rows, the weight and what the walk does with its two lerped-row registers (reuse both /
-// shift / read both / extrapolated row), per sample column the two cells and the weight, per
-// output row its band.  The main kernel's row loop is unrolled over the sample rows, so the
-// loop control is a handful of scalar instructions per row.
+// rows, the weight and what the walk does with its two lerped-row register sets (reuse both /
+// shift / read both / row outside the image), per sample column the two cells and the weight,
+// per output row its band.
+//
+// What the main kernel is built around (each item measured on the 600x1000 workload, 64 images):
+//  * its 16 waves claim RoIs four at a time from an LDS counter (a fixed share per wave left
+//    a tenth of the workgroup's time idle);
+//  * the sample-row step is one assembly statement: conditional refills of the row sets become
+//    branches the compiler cannot answer with register copies (it added ~20 v_mov_b64 per row to
+//    every C++ formulation), the LDS reads of a row are issued a row ahead into pinned registers;
+//  * workgroup n runs on XCD n % 8, and the 16 channel groups of one (image, band) go to one XCD;
+//  * 96 VGPRs and 137 KB of LDS: one wave per SIMD and 23 KB of LDS stay free for the small
+//    kernels of other streams, which otherwise keep a band workgroup waiting for a whole CU.
+// It is bound by vector-ALU issue (76 % busy) at the 2.0 GHz the chip holds while 12.85 GB of
+// stores are in flight; with the stores skipped the same code takes 2.6 ms at 2.4 GHz, the
+// stores alone 2.3 ms, together 3.25 ms.
 //
 // Arithmetic and its order are those of frcnn_roi.hip (top = TL + (TR-TL)*lx; bottom likewise;
 // out = top + (bottom-top)*ly; first maximum wins).  gfx950, wave64, -ffp-contract=off.
@@ -599,7 +611,7 @@ extern "C" size_t frcnn_roi_fwd_workspace_bytes(int B, int R) {
 // The band kernel wins once its workgroups (B * C/32 * bands, one per CU at a time) fill the
 // chip about three times over: on the 600x1000 workload (C = 512, R = 2000, 3 bands) it takes
 // 0.66 / 1.79 / 3.38 ms at B = 16 / 32 / 64 against 1.02 / 1.94 / 3.92 ms for the per-RoI
-// kernel, and loses below (0.56 vs 0.52 ms at B = 8).  A band is loaded once per workgroup
+// kernel, and loses below (0.54 vs 0.51 ms at B = 8).  A band is loaded once per workgroup
 // whatever R is: below about a thousand RoIs per image the per-RoI kernel is the faster one.
 // FRCNN_ROI_BAND_MIN_WG = n replaces the first threshold and lifts the second (n < 0: never).
 static bool band_wanted(int B, int H, int W, int C, int R, int crop_h, int crop_w, int pool,
