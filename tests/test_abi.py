@@ -54,6 +54,38 @@ def test_bad_arguments_are_rejected_without_a_gpu():
                               one, one, one, one, one, one, one, None) == _lib.E_BADARG
 
 
+def test_roi_forward_plan_and_prepare_argument_checks(monkeypatch):
+    """Which RoI forward kernel a call gets is host logic (no launch): the band-resident kernel
+    from 768 workgroups (B * C/32 * bands) and 1,024 RoIs per image on, the per-RoI one below;
+    FRCNN_ROI_BAND_MIN_WG moves the threshold."""
+    from objectdetection_amd import _lib, ops
+    L = _lib.lib
+    monkeypatch.delenv("FRCNN_ROI_BAND_MIN_WG", raising=False)
+    assert L.frcnn_roi_fwd_plan(64, 37, 62, 512, 2000, 14, 14, 2, 0) == 1      # 64 x 16 x 3 bands
+    assert L.frcnn_roi_fwd_plan(16, 37, 62, 512, 2000, 14, 14, 2, 1) == 1      # 768 workgroups
+    assert L.frcnn_roi_fwd_plan(15, 37, 62, 512, 2000, 14, 14, 2, 0) == 0
+    assert L.frcnn_roi_fwd_plan(64, 37, 62, 512, 1000, 14, 14, 2, 0) == 0      # few RoIs per image
+    assert L.frcnn_roi_fwd_plan(64, 37, 62, 500, 2000, 14, 14, 2, 0) == 0      # C % 32
+    assert L.frcnn_roi_fwd_plan(64, 37, 62, 512, 2000, 18, 18, 2, 0) == 0      # crop > 16
+    assert L.frcnn_roi_fwd_plan(64, 37, 62, 512, 2000, 14, 14, 1, 1) == 0      # plain crop + winner
+    assert L.frcnn_roi_fwd_plan(16, 48, 48, 512, 1500, 14, 14, 2, 0) == 1      # the ship workload
+    assert L.frcnn_roi_fwd_plan(0, 37, 62, 512, 2000, 14, 14, 2, 0) == 0
+    assert ops.roi_fwd_kernel_name(64, 37, 62, 512, 2000, (14, 14), 2) == "roi_fwd_band_kernel<2,false>"
+    assert ops.roi_fwd_kernel_name(8, 37, 62, 512, 2000, (14, 14), 2, True) == "roi_fwd_stage_kernel<2,true>"
+    monkeypatch.setenv("FRCNN_ROI_BAND_MIN_WG", "1")
+    assert L.frcnn_roi_fwd_plan(1, 9, 11, 64, 30, 14, 14, 2, 0) == 1
+    monkeypatch.setenv("FRCNN_ROI_BAND_MIN_WG", "-1")
+    assert L.frcnn_roi_fwd_plan(64, 37, 62, 512, 2000, 14, 14, 2, 0) == 0
+    monkeypatch.delenv("FRCNN_ROI_BAND_MIN_WG")
+    one = ctypes.c_void_p(16)
+    assert L.frcnn_roi_fwd_workspace_bytes(64, 2000) == 64 * 2000 * 272
+    assert L.frcnn_roi_fwd_prepare(None, 64, 37, 62, 512, 2000, 14, 14, 2, 0, one, 1 << 30, None) == _lib.E_BADARG
+    # nothing to prepare: small call, missing or short workspace (no launch in any of these)
+    assert L.frcnn_roi_fwd_prepare(one, 8, 37, 62, 512, 2000, 14, 14, 2, 0, one, 1 << 30, None) == 0
+    assert L.frcnn_roi_fwd_prepare(one, 64, 37, 62, 512, 2000, 14, 14, 2, 0, None, 0, None) == 0
+    assert L.frcnn_roi_fwd_prepare(one, 64, 37, 62, 512, 2000, 14, 14, 2, 0, one, 1000, None) == 0
+
+
 def test_no_product_module_imports_the_oracle():
     pkg = os.path.join(ROOT, "objectdetection_amd")
     for dp, _, fs in os.walk(pkg):
