@@ -48,9 +48,8 @@ constexpr int BD_RING = 4;                     // descriptors a wave keeps in LD
 constexpr int BD_PIECES = BD_RING / 4;         // 16-byte descriptor pieces a lane moves per claim
 static_assert(BD_RING % 4 == 0, "a wave moves four descriptors (64 pieces) per instruction");
 constexpr int BD_ENTRY = 256;                  // bytes of a descriptor's y and x parts
-constexpr int BD_HDR = 16;                     // bytes of a ring header {roi, rows, rows_direct}
 constexpr int BD_LDS_TOTAL = 160 * 1024;
-constexpr int BD_LDS_RING = BD_WAVES * BD_RING * (BD_ENTRY + BD_HDR);
+constexpr int BD_LDS_RING = BD_WAVES * BD_RING * BD_ENTRY;
 constexpr int BD_LDS_BUDGET = BD_LDS_TOTAL - BD_LDS_RING - 64;      // bytes left for the band
 constexpr uint32_t BD_DIRECT = 255, BD_NONE = 254;
 
@@ -165,18 +164,6 @@ __device__ __forceinline__ uint32_t bd_rl(uint32_t v, int lane) {
 }
 __device__ __forceinline__ uint32_t bd_first(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-}
-
-// bits p of the output rows whose band byte equals `want`
-__device__ __forceinline__ uint32_t band_match(uint4 w, uint32_t want) {
-    uint32_t m = 0;
-    const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-            if (((ws[j] >> (8 * t)) & 0xFFu) == want) m |= 1u << (4 * j + t);
-    return m;
 }
 
 // One sample row of the walk, written in assembly: the conditional refills of the two row sets
@@ -337,8 +324,6 @@ roi_fwd_band_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
     const uint32_t lds_adj = lds_base + (uint32_t)quad * 16u - (uint32_t)r0 * rowpitch;
     // this wave's descriptor ring (private: no barrier, LDS operations of a wave stay in order)
     unsigned char* ring = band_lds + (size_t)T * rowpitch + (size_t)wave * BD_RING * BD_ENTRY;
-    unsigned char* hdr = band_lds + (size_t)T * rowpitch + (size_t)BD_WAVES * BD_RING * BD_ENTRY +
-                         (size_t)wave * BD_RING * BD_HDR;
 
     // The waves of a workgroup claim the image's RoIs BD_RING at a time from a counter in LDS (a
     // fixed share per wave leaves the faster waves idle for a tenth of the workgroup's time) and
@@ -355,17 +340,29 @@ roi_fwd_band_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
         return (int)bd_first(n);
     };
-    auto fetch = [&](int n, uint4 (&piece)[BD_PIECES], uint4& bw) {
+    // the claimed descriptors -> this wave's ring; which output rows of each of them lie in this
+    // band (lane = (descriptor, output row) compares one band byte, a ballot collects the rows:
+    // bits 16 e .. 16 e + 15 of word t belong to descriptor 4 t + e)
+    auto fetch = [&](int n, uint64_t (&mine)[BD_PIECES], uint64_t (&mine_direct)[BD_PIECES]) {
+        uint4 piece[BD_PIECES];
+        uint32_t bandbyte[BD_PIECES];
 #pragma unroll
         for (int t = 0; t < BD_PIECES; ++t) {
             const int rr = n + sel + 4 * t;
             piece[t] = make_uint4(0u, 0u, 0u, 0u);
-            if (rr < R)
+            bandbyte[t] = BD_NONE;
+            if (rr < R) {
                 piece[t] = *reinterpret_cast<const uint4*>(
                     reinterpret_cast<const unsigned char*>(dimg + rr) + part * 16);
+                bandbyte[t] = reinterpret_cast<const unsigned char*>(dimg[rr].band)[part];
+            }
         }
-        bw = make_uint4(0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu);
-        if (lane < BD_RING && n + lane < R) bw = *reinterpret_cast<const uint4*>(dimg[n + lane].band);
+#pragma unroll
+        for (int t = 0; t < BD_PIECES; ++t) {
+            *reinterpret_cast<uint4*>(ring + (sel + 4 * t) * BD_ENTRY + part * 16) = piece[t];
+            mine[t] = __ballot(bandbyte[t] == (uint32_t)k);
+            mine_direct[t] = k == 0 ? __ballot(bandbyte[t] == BD_DIRECT) : 0ull;
+        }
     };
     f32x4 stg[8];                                // cells of a feature row on their way to a row set
 #pragma unroll
@@ -373,26 +370,20 @@ roi_fwd_band_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
     int n_cur = claim();
 #pragma unroll 1
     while (n_cur < R) {
-        {
-            uint4 piece[BD_PIECES], bw;
-            fetch(n_cur, piece, bw);
-#pragma unroll
-            for (int t = 0; t < BD_PIECES; ++t)
-                *reinterpret_cast<uint4*>(ring + (sel + 4 * t) * BD_ENTRY + part * 16) = piece[t];
-            const uint32_t mine = band_match(bw, (uint32_t)k);
-            const uint32_t mine_direct = k == 0 ? band_match(bw, BD_DIRECT) : 0u;
-            if (lane < BD_RING)
-                *reinterpret_cast<uint4*>(hdr + lane * BD_HDR) =
-                    make_uint4((uint32_t)(n_cur + lane), mine, mine_direct, 0u);
-        }
-        const int n_next = claim();
-        n_cur = n_next;
+        uint64_t mine[BD_PIECES], mine_direct[BD_PIECES];
+        fetch(n_cur, mine, mine_direct);
+        const int n_base = n_cur;
+        n_cur = claim();
         {
 #pragma unroll 1
             for (int vi = 0; vi < BD_RING; ++vi) {
-            const uint4 hv = *reinterpret_cast<const uint4*>(hdr + vi * BD_HDR);
-            const int r = (int)bd_first(hv.x);
-            const uint32_t rows = bd_first(hv.y), rows_direct = bd_first(hv.z);
+            uint64_t mw = mine[0], dw = mine_direct[0];
+#pragma unroll
+            for (int t = 1; t < BD_PIECES; ++t)
+                if ((vi >> 2) == t) { mw = mine[t]; dw = mine_direct[t]; }
+            const uint32_t rows = (uint32_t)(mw >> (16 * (vi & 3))) & 0xFFFFu;
+            const uint32_t rows_direct = (uint32_t)(dw >> (16 * (vi & 3))) & 0xFFFFu;
+            const int r = n_base + vi;
             if ((rows | rows_direct) == 0u) continue;                               // uniform
             uint32_t ydv = *reinterpret_cast<const uint32_t*>(ring + vi * BD_ENTRY + (lane & 31) * 4);
             const uint4 xdv = *reinterpret_cast<const uint4*>(ring + vi * BD_ENTRY + 128 + q * 16);
@@ -621,7 +612,7 @@ static bool band_wanted(int B, int H, int W, int C, int R, int crop_h, int crop_
     long long min_wg = 768;
     int min_roi = 1024;
     if (const char* e = getenv("FRCNN_ROI_BAND_MIN_WG")) { min_wg = atoll(e); min_roi = 1; }
-    return plan.ok && crop_h <= BD_MAXCROP && crop_w <= BD_MAXCROP && H < 4096 && W < 4096 &&
+    return plan.ok && plan.nb < (int)BD_NONE && crop_h <= BD_MAXCROP && crop_w <= BD_MAXCROP && H < 4096 && W < 4096 &&
            min_wg >= 0 && (long long)B * (C / BD_CG) * plan.nb >= min_wg &&
            (long long)B * (C / BD_CG) * plan.nb <= 0x7FFFFFFFll && R >= min_roi &&
            !(pool == 1 && want_winner);
