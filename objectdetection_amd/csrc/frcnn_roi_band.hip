@@ -59,7 +59,7 @@ constexpr uint32_t BD_DIRECT = 255, BD_NONE = 254;
 // and into which set the ceil row goes (`par`: the sets swap roles whenever exactly one row
 // is added, so nothing is ever moved between registers).
 // y[2s] = lo | hi << 12 | ok << 24 | par << 25 | action << 26, y[2s+1] = weight bits
-// x[2s] = lo | hi << 12 | ok << 24, x[2s+1] = weight bits             (sample column s)
+// x[2s] = lo | hi << 12 | ok << 24 | RoI flags << 25, x[2s+1] = weight bits   (sample column s)
 // band byte p = band of output row p (BD_DIRECT: no band holds it, BD_NONE: no such row)
 constexpr uint32_t BD_REUSE = 0, BD_SHIFT = 1, BD_BOTH = 2;
 struct RoiDesc { uint32_t y[2 * BD_MAXCROP]; uint32_t x[2 * BD_MAXCROP]; uint32_t band[4]; };
@@ -119,11 +119,19 @@ roi_band_prep_kernel(const float4* __restrict__ rois, int n_roi, int H, int W, i
                       (act << 26);
         d->y[2 * s + 1] = __float_as_uint(fr);
     }
+    uint32_t xflags = 1u << 26;                  // bit 25: a column outside, bit 26: hi = lo + 1 throughout
+    for (int s = 0; s < cw; ++s) {
+        int lo = 0, hi = 0, ok = 0;
+        float fr = 0.f;
+        axis_sample(box.y, box.w, W, cw, s, lo, hi, fr, ok);
+        if (!ok) xflags |= 1u << 25;
+        else if (hi != lo + 1) xflags &= ~(1u << 26);
+    }
     for (int s = 0; s < BD_MAXCROP; ++s) {
         int lo = 0, hi = 0, ok = 0;
         float fr = 0.f;
         if (s < cw) axis_sample(box.y, box.w, W, cw, s, lo, hi, fr, ok);
-        d->x[2 * s] = (uint32_t)lo | ((uint32_t)hi << 12) | ((uint32_t)ok << 24);
+        d->x[2 * s] = (uint32_t)lo | ((uint32_t)hi << 12) | ((uint32_t)ok << 24) | xflags;
         d->x[2 * s + 1] = __float_as_uint(fr);
     }
     for (int j = 0; j < 4; ++j) d->band[j] = bandw[j];
@@ -186,6 +194,19 @@ __device__ __forceinline__ uint32_t bd_first(uint32_t v) {
     "ds_read_b128 v[" R3 "], v" R3A "\n"
 #define BD_ISSUE_LO(OFF) BD_ISSUE(OFF, "80:83", "84:87", "88:91", "92:95", "80", "84", "88", "92")
 #define BD_ISSUE_HI(OFF) BD_ISSUE(OFF, "64:67", "68:71", "72:75", "76:79", "64", "68", "72", "76")
+// the same for a RoI whose every sample column has its right cell next to its left cell (all
+// but boxes with an edge exactly on a feature column): two address adds instead of four, the
+// right cells through the 128-byte immediate offset.  The address sits in the SECOND tuple's
+// first register, which only that tuple's own read overwrites.
+#define BD_ISSUE_REG(OFF, R0, R1, R2, R3, R1A, R3A)                                          \
+    "v_add_u32 v" R1A ", " OFF ", %[a0]\n"                                                   \
+    "v_add_u32 v" R3A ", " OFF ", %[a2]\n"                                                   \
+    "ds_read_b128 v[" R0 "], v" R1A "\n"                                                     \
+    "ds_read_b128 v[" R1 "], v" R1A " offset:128\n"                                          \
+    "ds_read_b128 v[" R2 "], v" R3A "\n"                                                     \
+    "ds_read_b128 v[" R3 "], v" R3A " offset:128\n"
+#define BD_ISSUE_LO_REG(OFF) BD_ISSUE_REG(OFF, "80:83", "84:87", "88:91", "92:95", "84", "92")
+#define BD_ISSUE_HI_REG(OFF) BD_ISSUE_REG(OFF, "64:67", "68:71", "72:75", "76:79", "68", "76")
 // set S <- the x-lerp of a staged row: four independent chains, dependent instructions four apart
 #define BD_XLERP(S, C0L, C0H, C1L, C1H, C2L, C2H, C3L, C3H)                                  \
     "v_pk_add_f32 v[" C1L "], v[" C1L "], v[" C0L "] neg_lo:[0,1] neg_hi:[0,1]\n"            \
@@ -223,17 +244,25 @@ __device__ __forceinline__ uint32_t bd_first(uint32_t v) {
 // so their latency passes behind the current row's y-lerp, its pooling and the next row's
 // scalar decode.  The staging registers are operands pinned to v[64:95]: they stay live from
 // one statement to the next.
-#define BD_ISSUE_NEXT(TAG)                                                                   \
+#define BD_ISSUE_NEXT3(TAG, LO, HI)                                                          \
     "s_bitcmp1_b32 %[ywn], 27\n"                                                             \
     "s_cbranch_scc0 .Lbd_n1" TAG "_%=\n"                                                     \
-    BD_ISSUE_LO("%[lon]")                                                                    \
-    BD_ISSUE_HI("%[hin]")                                                                    \
+    LO("%[lon]")                                                                             \
+    HI("%[hin]")                                                                             \
     "s_branch .Lbd_n0" TAG "_%=\n"                                                           \
     ".Lbd_n1" TAG "_%=:\n"                                                                   \
     "s_bitcmp1_b32 %[ywn], 26\n"                                                             \
     "s_cbranch_scc0 .Lbd_n0" TAG "_%=\n"                                                     \
-    BD_ISSUE_HI("%[hin]")                                                                    \
+    HI("%[hin]")                                                                             \
     ".Lbd_n0" TAG "_%=:\n"
+#define BD_ISSUE_NEXT(TAG)                                                                   \
+    "s_cmp_lg_u32 %[xreg], 0\n"                                                              \
+    "s_cbranch_scc1 .Lbd_nr" TAG "_%=\n"                                                     \
+    BD_ISSUE_NEXT3(TAG "i", BD_ISSUE_LO, BD_ISSUE_HI)                                        \
+    "s_branch .Lbd_ne" TAG "_%=\n"                                                           \
+    ".Lbd_nr" TAG "_%=:\n"                                                                   \
+    BD_ISSUE_NEXT3(TAG "r", BD_ISSUE_LO_REG, BD_ISSUE_HI_REG)                                \
+    ".Lbd_ne" TAG "_%=:\n"
 #define BD_ROWSTEP_HALF(TAG, SETLO, SETHI)                                                   \
     "s_bitcmp1_b32 %[yw], 27\n"                                                              \
     "s_cbranch_scc0 .Lbd_one" TAG "_%=\n"                                                    \
@@ -389,12 +418,21 @@ roi_fwd_band_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
             const uint4 xdv = *reinterpret_cast<const uint4*>(ring + vi * BD_ENTRY + 128 + q * 16);
             const uint32_t xlo0 = xdv.x & 0xFFFu, xhi0 = (xdv.x >> 12) & 0xFFFu;
             const uint32_t xlo1 = xdv.z & 0xFFFu, xhi1 = (xdv.z >> 12) & 0xFFFu;
-            const bool ok0 = live0 && ((xdv.x >> 24) & 1u), ok1 = live1 && ((xdv.z >> 24) & 1u);
             const float fx0 = __uint_as_float(xdv.y), fx1 = __uint_as_float(xdv.w);
-            // lanes whose sample column lies outside the image: their samples are zeros
-            const uint64_t xout0 = __ballot(live0 && !ok0), xout1 = __ballot(live1 && !ok1);
-            const uint32_t a0 = xlo0 * BD_CELL + lds_adj, a1 = xhi0 * BD_CELL + lds_adj;
-            const uint32_t a2 = xlo1 * BD_CELL + lds_adj, a3 = xhi1 * BD_CELL + lds_adj;
+            // two facts about the RoI's sample columns ride in every x word: bit 25 = some column
+            // lies outside the image, bit 26 = every column inside has its right cell next to
+            // its left cell
+            const uint32_t xflags = bd_first(xdv.x) >> 25;
+            const uint32_t xregular = (xflags >> 1) & 1u;
+            bool ok0 = live0, ok1 = live1;
+            uint64_t xout0 = 0ull, xout1 = 0ull;     // lanes whose samples are zeros
+            if (xflags & 1u) {                                                       // uniform
+                ok0 = live0 && ((xdv.x >> 24) & 1u); ok1 = live1 && ((xdv.z >> 24) & 1u);
+                xout0 = __ballot(live0 && !ok0); xout1 = __ballot(live1 && !ok1);
+            }
+            const uint32_t a0 = xlo0 * BD_CELL + lds_adj, a2 = xlo1 * BD_CELL + lds_adj;
+            uint32_t a1 = a0, a3 = a2;               // unused by a regular RoI
+            if (!xregular) { a1 = xhi0 * BD_CELL + lds_adj; a3 = xhi1 * BD_CELL + lds_adj; }
             const size_t roi_out = ((size_t)b * R + r) * (size_t)(PH * PW) * C;        // uniform
             float* oroi = out + roi_out + lane_out;
             uint8_t* wroi = WIN ? winner + roi_out + lane_out : nullptr;
@@ -455,7 +493,7 @@ roi_fwd_band_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
                     asm volatile(BD_ISSUE_NEXT("p")
                                  : BD_STAGING(stg)
                                  : [a0] "v"(la0), [a1] "v"(la1), [a2] "v"(la2), [a3] "v"(la3),
-                                   [ywn] "s"(ywn), [lon] "s"(lon), [hin] "s"(hin)
+                                   [ywn] "s"(ywn), [lon] "s"(lon), [hin] "s"(hin), [xreg] "s"(xregular)
                                  : "scc");
                 }
 #pragma unroll 1
@@ -503,7 +541,7 @@ roi_fwd_band_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
                               BD_STAGING(stg), [tmp] "=&s"(exec_tmp)
                             : [a0] "v"(la0), [a1] "v"(la1), [a2] "v"(la2), [a3] "v"(la3),
                               [fx0] "v"(fx0p), [fx1] "v"(fx1p), [yw] "s"(yw), [fy] "s"(fy),
-                              [ywn] "s"(ywn), [lon] "s"(lon), [hin] "s"(hin),
+                              [ywn] "s"(ywn), [lon] "s"(lon), [hin] "s"(hin), [xreg] "s"(xregular),
                               [xout0] "s"(xout0), [xout1] "s"(xout1)
                             : "scc");
                         fold(oy, ky, v0, v1);
