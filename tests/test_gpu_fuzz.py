@@ -163,6 +163,41 @@ def test_fuzz_roi_forward_backward(seed, B, H, W, C, R, cp, mode, strided):
 
 
 @FUZZ
+@given(seed=st.integers(0, 2**31 - 1), B=st.integers(1, 2), H=st.integers(1, 90),
+       W=st.integers(1, 40), C=st.sampled_from([32, 64, 96, 160]), R=st.integers(1, 40), cp=CROPS,
+       mode=BOX_MODES, prepared=st.booleans())
+@example(seed=21, B=2, H=90, W=40, C=64, R=40, cp=((14, 14), 2), mode="outside", prepared=True)
+@example(seed=22, B=1, H=1, W=1, C=32, R=7, cp=((14, 14), 2), mode="uniform", prepared=False)
+@example(seed=23, B=1, H=80, W=1, C=96, R=33, cp=((16, 16), 2), mode="grid", prepared=True)
+@example(seed=24, B=2, H=2, W=37, C=160, R=5, cp=((1, 1), 1), mode="degenerate", prepared=False)
+def test_fuzz_roi_forward_band_kernel(seed, B, H, W, C, R, cp, mode, prepared):
+    """The band-resident forward kernel (forced on at these sizes) on maps of one to many bands,
+    in one call and as prepare + run; the pool = 1 winner case falls back to the per-RoI kernel."""
+    import os
+    from objectdetection_amd import ops
+    crop, pool = cp
+    rng = np.random.default_rng(seed)
+    fm = rng.standard_normal((B, H, W, C)).astype(np.float32)
+    prop = np.stack([draw_boxes(rng, R, mode) for _ in range(B)])
+    ws = torch.empty(ops.roi_fwd_workspace_bytes(B, R), dtype=torch.uint8, device=DEV)
+    old = os.environ.get("FRCNN_ROI_BAND_MIN_WG")
+    os.environ["FRCNN_ROI_BAND_MIN_WG"] = "1"
+    try:
+        ready = prepared and ops.roi_fwd_prepare(T(prop), fm.shape, crop, pool, pool > 1, ws)
+        out, win = ops.roi_crop_pool_fwd(T(fm), T(prop), crop, pool, want_winner=pool > 1,
+                                         workspace=ws, prepared=ready)
+    finally:
+        if old is None:
+            del os.environ["FRCNN_ROI_BAND_MIN_WG"]
+        else:
+            os.environ["FRCNN_ROI_BAND_MIN_WG"] = old
+    ro, ra = O.roi_crop_pool(fm, prop, crop, pool)
+    np.testing.assert_array_equal(out.cpu().numpy(), ro)
+    if pool > 1:
+        np.testing.assert_array_equal(win.cpu().numpy(), ra)
+
+
+@FUZZ
 @given(seed=st.integers(0, 2**31 - 1), B=st.integers(1, 3), R=st.integers(1, 600),
        G=st.integers(1, 60), batch=st.sampled_from([8, 64, 128]), mode=BOX_MODES)
 @example(seed=10, B=3, R=600, G=60, batch=128, mode="clustered")
