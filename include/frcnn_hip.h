@@ -191,7 +191,7 @@ int frcnn_roi_crop_pool_fwd(const float* fmap, int B, int H, int W, int C,
  * and at least 1024 RoIs per image, the layout is channels-last with C % 32 == 0 and the crop at
  * most 16 x 16; every other call is forwarded to frcnn_roi_crop_pool_fwd, so the entry point
  * accepts whatever that one accepts.  On the 600x1000 workload (C = 512, R = 2000) the band
- * kernel takes 3.25 ms per 64 images against 4.0 ms for the per-RoI kernel, and loses below 16
+ * kernel takes 3.16 ms per 64 images against 4.0 ms for the per-RoI kernel, and loses below 16
  * images per call.  The environment variable FRCNN_ROI_BAND_MIN_WG = n replaces the workgroup
  * threshold and lifts the RoI threshold (n < 0: never).  frcnn_roi_fwd_plan tells which kernel
  * a call with a channels-last, 16-byte aligned map and a full workspace would run (1: band,

@@ -28,9 +28,9 @@
 //  * workgroup n runs on XCD n % 8, and the 16 channel groups of one (image, band) go to one XCD;
 //  * 96 VGPRs and 137 KB of LDS: one wave per SIMD and 23 KB of LDS stay free for the small
 //    kernels of other streams, which otherwise keep a band workgroup waiting for a whole CU.
-// It is bound by vector-ALU issue (76 % busy) at the 2.0 GHz the chip holds while 12.85 GB of
-// stores are in flight; with the stores skipped the same code takes 2.6 ms at 2.4 GHz, the
-// stores alone 2.3 ms, together 3.25 ms.
+// It is bound by its stores and by vector-ALU issue (67 % busy), about level, at the 2.0 GHz the
+// chip holds while 12.85 GB of stores are in flight: the stores alone take 2.3 ms, the vector
+// instructions 1.75 ms at 2.4 GHz, together 3.16 ms.
 //
 // Arithmetic and its order are those of frcnn_roi.hip (top = TL + (TR-TL)*lx; bottom likewise;
 // out = top + (bottom-top)*ly; first maximum wins).  gfx950, wave64, -ffp-contract=off.
