@@ -122,14 +122,16 @@ __device__ __forceinline__ unsigned long long mask_tile(const NBox& a, float c1,
             const NBox cb = grp[u];
             const float iy0 = vmax2(a.y0, cb.y0), ix0 = vmax2(a.x0, cb.x0);
             const float iy1 = vmin2(a.y1, cb.y1), ix1 = vmin2(a.x1, cb.x1);
-            const float inter = vmax2(iy1 - iy0, 0.0f) * vmax2(ix1 - ix0, 0.0f);
-            bool p = inter * c1 > a.t + cb.t;
-            if (DIAG) p = p && (c > lane);
-            if (__any(p)) {
+            // the filter: one clamp is enough (a zero height zeroes the product, a negative width
+            // makes it negative: neither passes), the product and the column's term in one fma
+            const float fil = vmax2(iy1 - iy0, 0.0f) * (ix1 - ix0);
+            unsigned long long w = __ballot(__builtin_fmaf(fil, c1, -cb.t) > a.t);
+            if (DIAG) w &= (1ull << c) - 1ull;                   // rows before the column only (lane < c)
+            if (w != 0ull) {                                                // uniform
+                const float inter = vmax2(iy1 - iy0, 0.0f) * vmax2(ix1 - ix0, 0.0f);
                 const float u2 = a.area + cb.area - inter;
-                p = p && (a.area > 0.0f) && (cb.area > 0.0f) && (inter / u2 > thr);
+                w &= __ballot((a.area > 0.0f) && (cb.area > 0.0f) && (inter / u2 > thr));
             }
-            const unsigned long long w = __ballot(p);
             if (lane == c) mine = w;
         }
     }
