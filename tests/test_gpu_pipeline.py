@@ -136,3 +136,25 @@ def test_planar_feature_map_gives_the_same_path(dev):
     b.run(planar, score, coord)
     torch.cuda.synchronize()
     assert torch.equal(a.pooled, b.pooled) and torch.equal(a.winner, b.winner)
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2 --backend gloo` from a bare shell on a one-GPU box: the script
+    spawns two ranks that share the card, each runs RegionProposalPath on its half of a global
+    batch of 32 images (16 per rank: the band-resident RoI kernel), rank 0 reports the whole job
+    and checks its last step against a plain rerun."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend",
+                          "gloo", "--global-batch", "32", "--steps", "3", "--warmup", "1",
+                          "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["verified"] is True
+    assert rec["config"]["global_batch"] == 32 and rec["config"]["images_per_gpu_per_step"] == 16
+    assert rec["roofline"]["kernel"] == "roi_fwd_band_kernel<2,false>"
