@@ -37,12 +37,31 @@ __device__ __forceinline__ unsigned long long same_digit(uint32_t dg, bool valid
     return peers;
 }
 
+// Workgroup n runs on XCD n % 8.  All blocks of an image go to one XCD (consecutive workgroups
+// of that XCD), so the scattered 4-byte writes of a pass meet in ONE L2 and leave it as whole
+// lines; spread over the eight L2s they left as partial lines, which the RoI kernel running
+// beside the sort paid for at the memory side.
+__device__ __forceinline__ void ts_block_of(int n, int nblk, int B, int& blk, int& b) {
+    const int full = B & ~7;                            // images that fill whole rounds of 8 XCDs
+    if (n < full * nblk) {
+        const int slot = n >> 3;
+        b = 8 * (slot / nblk) + (n & 7);
+        blk = slot % nblk;
+    } else {
+        const int m = n - full * nblk;
+        b = full + m / nblk;
+        blk = m % nblk;
+    }
+}
+
 template <int PASS>
 __global__ void __launch_bounds__(64)
 ts_hist_kernel(const float* __restrict__ scores, const uint32_t* __restrict__ keys_in, int N,
-               int nblk, uint32_t* __restrict__ hist) {
+               int nblk, int B, uint32_t* __restrict__ hist) {
     __shared__ uint32_t h[256];
-    const int blk = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int lane = threadIdx.x;
+    int blk, b;
+    ts_block_of((int)blockIdx.x, nblk, B, blk, b);
 #pragma unroll
     for (int t = 0; t < 4; ++t) h[t * 64 + lane] = 0;
     __builtin_amdgcn_wave_barrier();
@@ -98,11 +117,13 @@ ts_offsets_kernel(int nblk, uint32_t* __restrict__ hist) {
 template <int PASS>
 __global__ void __launch_bounds__(64)
 ts_scatter_kernel(const float* __restrict__ scores, const uint32_t* __restrict__ keys_in,
-                  const int32_t* __restrict__ idx_in, int N, int nblk,
+                  const int32_t* __restrict__ idx_in, int N, int nblk, int B,
                   const uint32_t* __restrict__ offsets, uint32_t* __restrict__ keys_out,
                   int32_t* __restrict__ idx_out) {
     __shared__ uint32_t nextpos[256];                // next output place of each digit
-    const int blk = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int lane = threadIdx.x;
+    int blk, b;
+    ts_block_of((int)blockIdx.x, nblk, B, blk, b);
     const uint32_t* off = offsets + ((size_t)b * nblk + blk) * 256;
 #pragma unroll
     for (int t = 0; t < 4; ++t) nextpos[t * 64 + lane] = off[t * 64 + lane];
@@ -186,11 +207,11 @@ extern "C" int frcnn_topk_sort(const float* scores, int B, int N, int K, const f
                        reinterpret_cast<int32_t*>(ws + 3 * plane)};
     uint32_t* hist = reinterpret_cast<uint32_t*>(ws + 4 * plane);
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid(nblk, B), block(64);
+    const dim3 grid((unsigned)((long long)nblk * B)), block(64);
 #define TS_PASS(P, KIN, IIN, KOUT, IOUT)                                                          \
-    FRCNN_LAUNCH(ts_hist_kernel<P>, grid, block, 0, st, scores, KIN, N, nblk, hist);              \
+    FRCNN_LAUNCH(ts_hist_kernel<P>, grid, block, 0, st, scores, KIN, N, nblk, B, hist);           \
     FRCNN_LAUNCH(ts_offsets_kernel, dim3(B), dim3(64), 0, st, nblk, hist);                       \
-    FRCNN_LAUNCH(ts_scatter_kernel<P>, grid, block, 0, st, scores, KIN, IIN, N, nblk, hist, KOUT, \
+    FRCNN_LAUNCH(ts_scatter_kernel<P>, grid, block, 0, st, scores, KIN, IIN, N, nblk, B, hist, KOUT, \
                  IOUT)
     TS_PASS(0, (const uint32_t*)nullptr, (const int32_t*)nullptr, keys[0], idx[0]);
     TS_PASS(1, keys[0], idx[0], keys[1], idx[1]);
