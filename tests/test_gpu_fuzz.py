@@ -89,6 +89,8 @@ def test_fuzz_anchor_assignment(seed, H, W, ns, nr, G, thr, mode):
 @example(seed=1, B=2, N=39999, kfrac=0.5, vals="few", method="sort")
 @example(seed=2, B=3, N=20000, kfrac=1.0, vals="zeros", method="lds")
 @example(seed=3, B=1, N=40000, kfrac=1.0, vals="equal", method="sort")
+@example(seed=12, B=11, N=2500, kfrac=0.3, vals="few", method="sort")     # 8 images XCD-ordered + 3 in order
+@example(seed=13, B=16, N=1025, kfrac=1.0, vals="normal", method="sort")
 def test_fuzz_topk(seed, B, N, kfrac, vals, method):
     from objectdetection_amd import ops
     rng = np.random.default_rng(seed)
