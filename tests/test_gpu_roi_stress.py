@@ -155,3 +155,26 @@ def test_store_data_survives_the_next_row(dev):
     assert len(bad) == 0, ("first mismatches (roi, p, q, channel):", bad[:6],
                            "channel quads", sorted(set((bad[:, 3] // 4 % 16).tolist())),
                            "components", sorted(set((bad[:, 3] % 4).tolist())))
+
+
+@pytest.mark.parametrize("B", [3, 5, 11])
+def test_band_kernel_workgroup_order(dev, monkeypatch, B):
+    """(image, band) pairs are dealt to the 8 XCDs in rounds of eight; a count that is not a
+    multiple of eight ends with pairs in plain order.  37x62 maps have three bands: B = 3, 5, 11
+    give 9, 15 and 33 pairs."""
+    from objectdetection_amd import ops
+    monkeypatch.setenv("FRCNN_ROI_BAND_MIN_WG", "1")
+    lib = c_oracle.load()
+    rng = np.random.default_rng(B)
+    H, W, C, R = 37, 62, 64, 60
+    assert ops.roi_fwd_kernel_name(B, H, W, C, R, (14, 14), 2).startswith("roi_fwd_band")
+    fm = rng.standard_normal((B, H, W, C)).astype(np.float32)
+    rois = np.stack([_boxes(rng, R, H, W) for _ in range(B)])
+    ws = torch.empty(ops.roi_fwd_workspace_bytes(B, R), dtype=torch.uint8, device=dev)
+    out, w = ops.roi_crop_pool_fwd(torch.tensor(fm, device=dev), torch.tensor(rois, device=dev),
+                                   (14, 14), 2, want_winner=True, workspace=ws)
+    for b in range(B):
+        ro, rw = c_oracle.roi_crop_pool(lib, fm[b], rois[b], (14, 14), 2, want_winner=True)
+        got = out[b].cpu().numpy()
+        assert ((got == ro) | (np.isnan(got) & np.isnan(ro))).all(), b
+        np.testing.assert_array_equal(w[b].cpu().numpy(), rw)
