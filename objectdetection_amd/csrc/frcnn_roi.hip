@@ -1021,28 +1021,47 @@ roi_bwd_cl_kernel(const float* __restrict__ dY, const uint8_t* __restrict__ winn
 // footprint contains this cell, and the (few) hits are walked by scalar loops.
 // Summation order per cell: RoI ascending, sample (sy,sx) row-major, corner
 // TL,TR,BL,BR.
-__device__ __forceinline__ bool axis_reaches(float c1, float c2, int dim, int n, int target) {
-    float first, last;
+// The source coordinate of sample s is base + s * scale (axis_sample's expression): base and
+// scale depend on the box only, so the lane that tests a RoI as a candidate computes them (one
+// division) and the lanes that evaluate its samples later take them by readlane.
+__device__ __forceinline__ void axis_line(float c1, float c2, int dim, int n, float& base,
+                                          float& scale) {
     if (n > 1) {
-        const float scale = ((c2 - c1) * (float)(dim - 1)) / (float)(n - 1);
-        first = c1 * (float)(dim - 1);
-        last = c1 * (float)(dim - 1) + (float)(n - 1) * scale;
+        scale = ((c2 - c1) * (float)(dim - 1)) / (float)(n - 1);
+        base = c1 * (float)(dim - 1);
     } else {
-        first = last = (float)(0.5 * (double)(c1 + c2) * (double)(dim - 1));
+        scale = 0.0f;
+        base = (float)(0.5 * (double)(c1 + c2) * (double)(dim - 1));
     }
-    const float lo = floorf(fminf(first, last)), hi = ceilf(fmaxf(first, last));
+}
+__device__ __forceinline__ bool line_reaches(float base, float scale, int n, int target) {
+    const float last = n > 1 ? base + (float)(n - 1) * scale : base;
+    const float lo = floorf(fminf(base, last)), hi = ceilf(fmaxf(base, last));
     return (float)target >= lo && (float)target <= hi;      // NaN -> false
+}
+__device__ __forceinline__ void line_sample(float base, float scale, int dim, int n, int s, int& lo,
+                                            int& hi, float& frac, int& ok) {
+    const float in = n > 1 ? base + (float)s * scale : base;
+    ok = (in >= 0.0f && in <= (float)(dim - 1));      // NaN -> extrapolated
+    const float f = floorf(in), c = ceilf(in);
+    frac = in - f;
+    lo = ok ? (int)f : 0;
+    hi = ok ? (int)c : 0;
 }
 
 // One candidate RoI applied to one cell.  ylo_m / yhi_m: sample rows whose floor / ceil row is
 // the cell's row, xlo_m / xhi_m likewise for columns; `fr` holds the lerp fraction of sample
 // row sy in lane ylane0 + sy and of sample column sx in lane xlane0 + sx.  Order: sample
 // (sy,sx) row-major, corner TL,TR,BL,BR.  cq = the lane's first channel quad.
+// The gradient and winner quads of the RoI come through buffer descriptors (base = the RoI's
+// first bin, records = its ph * pw * C elements): a pair's address is one scalar offset
+// (bin * C) next to the lane's fixed vector offset, and lanes beyond C carry an offset past
+// the records, so they read 0 without a branch.
 template <int POOL, int NQ>
 __device__ __forceinline__ void bwd_apply_candidate(
-    float4 (&acc)[NQ], const float* __restrict__ dY, const uint8_t* __restrict__ winner,
-    size_t rbase, int pw, int C, int C4, int cq, uint32_t ylo_m, uint32_t yhi_m, uint32_t xlo_m,
-    uint32_t xhi_m, float fr, int ylane0, int xlane0) {
+    float4 (&acc)[NQ], __amdgpu_buffer_rsrc_t gbuf, __amdgpu_buffer_rsrc_t wbuf, int pw, int C,
+    const uint32_t (&voff_g)[NQ], const uint32_t (&voff_w)[NQ], uint32_t ylo_m, uint32_t yhi_m,
+    uint32_t xlo_m, uint32_t xhi_m, float fr, int ylane0, int xlane0) {
     uint32_t ym = ylo_m | yhi_m;
     const uint32_t xm_all = xlo_m | xhi_m;
     if (ym == 0u || xm_all == 0u) return;
@@ -1052,6 +1071,7 @@ __device__ __forceinline__ void bwd_apply_candidate(
         const float ly = rlf(fr, ylane0 + sy);
         const bool top = (ylo_m >> sy) & 1u, bot = (yhi_m >> sy) & 1u;
         const float wt = 1.0f - ly, wb = ly;
+        const uint32_t rowbin = (uint32_t)((sy / POOL) * pw);
         uint32_t xm = xm_all;
         while (xm != 0u) {
             const int sx = __ffs((int)xm) - 1;
@@ -1060,20 +1080,15 @@ __device__ __forceinline__ void bwd_apply_candidate(
             const bool left = (xlo_m >> sx) & 1u, right = (xhi_m >> sx) & 1u;
             const float wl = 1.0f - lx, wr = lx;
             const uint32_t k = (uint32_t)((sy % POOL) * POOL + (sx % POOL));
-            const size_t o = rbase + (size_t)((sy / POOL) * pw + (sx / POOL)) * C;
+            const uint32_t soff = (rowbin + (uint32_t)(sx / POOL)) * (uint32_t)C;   // elements
             // all loads of the pair go out before the first use
             float4 gq[NQ];
             uint32_t wq[NQ];
 #pragma unroll
             for (int u = 0; u < NQ; ++u) {
-                const int c4 = cq + 64 * u;
-                gq[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                wq[u] = 0u;
-                if (c4 < C4) {
-                    gq[u] = *reinterpret_cast<const float4*>(dY + o + c4 * 4);
-                    if (POOL > 1)
-                        wq[u] = *reinterpret_cast<const uint32_t*>(winner + o + c4 * 4);
-                }
+                gq[u] = buf_load4(gbuf, voff_g[u], soff * 4u);
+                wq[u] = POOL > 1 ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(wbuf, voff_w[u], soff, 0)
+                                 : 0u;
             }
             if (POOL > 1) {
                 // a non-winner channel adds +0 (x + 0 == x): same value as skipping it
@@ -1142,6 +1157,15 @@ roi_bwd_wave_kernel(const float* __restrict__ dY, const uint8_t* __restrict__ wi
         acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r_begin > 0 && c4 < C4) acc[u] = *reinterpret_cast<const float4*>(dst + c4 * 4);
     }
+    // this lane's byte offsets inside a bin; past every record for channels beyond C
+    uint32_t voff_g[NQ], voff_w[NQ];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+        const int c4 = cq + 64 * u;
+        voff_g[u] = c4 < C4 ? (uint32_t)c4 * 16u : 0x7FFFFFF0u;
+        voff_w[u] = c4 < C4 ? (uint32_t)c4 * 4u : 0x7FFFFFF0u;
+    }
+    const uint32_t roi_elems = (uint32_t)(ph * pw) * (uint32_t)C;
     const float4* rb = rois + (size_t)b * R;
     const int field = lane / LW;
     const int ci = field >> 1;                               // this lane's candidate of the group
@@ -1152,11 +1176,13 @@ roi_bwd_wave_kernel(const float* __restrict__ dY, const uint8_t* __restrict__ wi
 #pragma unroll 1
     for (int r0 = r_begin; r0 < r_end; r0 += 64) {
         const int r = r0 + lane;
-        float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 line = make_float4(0.f, 0.f, 0.f, 0.f);        // y base, x base, y scale, x scale
         bool cand = false;
         if (r < r_end) {
-            box = rb[r];
-            cand = axis_reaches(box.x, box.z, H, ch, y) && axis_reaches(box.y, box.w, W, cw, x);
+            const float4 box = rb[r];
+            axis_line(box.x, box.z, H, ch, line.x, line.z);
+            axis_line(box.y, box.w, W, cw, line.y, line.w);
+            cand = line_reaches(line.x, line.z, ch, y) && line_reaches(line.y, line.w, cw, x);
         }
         unsigned long long m = __ballot(cand);
 #pragma unroll 1
@@ -1172,15 +1198,15 @@ roi_bwd_wave_kernel(const float* __restrict__ dY, const uint8_t* __restrict__ wi
                     lc[t] = __ffsll((long long)m) - 1;
                     m &= m - 1ull;
                     nc = t + 1;
-                    const float by1 = rlf(box.x, lc[t]), bx1 = rlf(box.y, lc[t]);
-                    const float by2 = rlf(box.z, lc[t]), bx2 = rlf(box.w, lc[t]);
+                    const float by1 = rlf(line.x, lc[t]), bx1 = rlf(line.y, lc[t]);
+                    const float by2 = rlf(line.z, lc[t]), bx2 = rlf(line.w, lc[t]);
                     if (ci == t) { c1 = isx ? bx1 : by1; c2 = isx ? bx2 : by2; }
                 }
             }
             int lo = 0, hi = 0, ok = 0;
             float fr = 0.f;
             const bool act = s < ns && ci < nc;
-            if (act) axis_sample(c1, c2, dim, ns, s, lo, hi, fr, ok);
+            if (act) line_sample(c1, c2, dim, ns, s, lo, hi, fr, ok);
             const bool v = act && ok;
             const unsigned long long mlo = __ballot(v && lo == target);
             const unsigned long long mhi = __ballot(v && hi == target);
@@ -1193,8 +1219,14 @@ roi_bwd_wave_kernel(const float* __restrict__ dY, const uint8_t* __restrict__ wi
             const uint32_t yhi_m = (uint32_t)(mhi >> sh) & FIELD;
             const uint32_t xlo_m = (uint32_t)(mlo >> (sh + LW)) & FIELD;
             const uint32_t xhi_m = (uint32_t)(mhi >> (sh + LW)) & FIELD;
-            const size_t rbase = ((size_t)b * R + (r0 + l)) * (size_t)(ph * pw) * C;
-            bwd_apply_candidate<POOL, NQ>(acc, dY, winner, rbase, pw, C, C4, cq, ylo_m, yhi_m,
+            if (((ylo_m | yhi_m) == 0u) || ((xlo_m | xhi_m) == 0u)) continue;
+            const size_t rbase = ((size_t)b * R + (r0 + l)) * (size_t)roi_elems;
+            const __amdgpu_buffer_rsrc_t gbuf = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(dY + rbase), 0, roi_elems * 4u, 0x00020000);
+            const __amdgpu_buffer_rsrc_t wbuf = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<uint8_t*>(POOL > 1 ? winner + rbase : nullptr), 0, POOL > 1 ? roi_elems : 0u,
+                0x00020000);
+            bwd_apply_candidate<POOL, NQ>(acc, gbuf, wbuf, pw, C, voff_g, voff_w, ylo_m, yhi_m,
                                           xlo_m, xhi_m, fr, sh, sh + LW);
             }
         }
@@ -1291,7 +1323,9 @@ extern "C" int frcnn_roi_crop_pool_bwd(const float* dY, const uint8_t* winner, c
     const dim3 grid(W, H, B), block(128);
     const float4* rb = reinterpret_cast<const float4*>(rois);
     hipStream_t st = (hipStream_t)stream;
-    if (crop_h <= 32 && crop_w <= 32) {
+    // the wave-per-cell kernel addresses a RoI's bins with 32-bit byte offsets
+    const bool roi_fits = (long long)(crop_h / pool) * (crop_w / pool) * C * 4 < 0x7FFFFFF0ll;
+    if (crop_h <= 32 && crop_w <= 32 && roi_fits) {
         const int nq = (C / 4 + 63) / 64;                 // channel quads per lane; above 8 the
                                                           // channels are split over blockIdx.y
         const int nqk = nq <= 1 ? 1 : nq <= 2 ? 2 : nq <= 4 ? 4 : 8;
