@@ -31,14 +31,3 @@ for _ in range(REPS):
 alg = dY.numel() * 4 + path.winner.numel() + g.numel() * 4
 print(f"roi bwd B={B}: min {min(ts):.3f} ms ({min(ts)/B*1e3:.1f} us/image)  "
       f"{alg/min(ts)/1e6:.1f} GB/s algorithmic")
-if os.environ.get("BWD_CHECK", "0") == "1":
-    keep = os.environ.get("FRCNN_BWD_KERNEL")
-    os.environ["FRCNN_BWD_KERNEL"] = "wave"
-    ref = ops.roi_crop_pool_bwd(dY, path.winner, path.proposed, tuple(fmap.shape), cfg.crop, cfg.pool)
-    torch.cuda.synchronize()
-    if keep is None:
-        del os.environ["FRCNN_BWD_KERNEL"]
-    else:
-        os.environ["FRCNN_BWD_KERNEL"] = keep
-    print("identical to the wave-per-cell kernel:", bool(torch.equal(ref, g)),
-          "max abs diff", float((ref - g).abs().max()))
