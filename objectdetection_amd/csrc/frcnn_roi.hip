@@ -1013,14 +1013,15 @@ roi_bwd_cl_kernel(const float* __restrict__ dY, const uint8_t* __restrict__ winn
     }
 }
 
-// ---- backward, fast path: one wave per feature cell, no LDS, no barrier.
-// Lane = RoI while candidates are detected (64 at a time, conservative reach
+// ---- backward, fast path: one wave per feature cell (or two neighbours of a row), no LDS,
+// no barrier.  Lane = RoI while candidates are detected (64 at a time, conservative reach
 // test, ballot), then lane = channel quad while a candidate is applied.  For a
 // candidate the wave evaluates all sample rows (lanes 0-31) and sample columns
 // (lanes 32-63) at once; ballots give the sample rows / columns whose bilinear
-// footprint contains this cell, and the (few) hits are walked by scalar loops.
+// footprint contains the wave's cells, and the (few) hits are walked by scalar loops.
 // Summation order per cell: RoI ascending, sample (sy,sx) row-major, corner
 // TL,TR,BL,BR.
+
 // The source coordinate of sample s is base + s * scale (axis_sample's expression): base and
 // scale depend on the box only, so the lane that tests a RoI as a candidate computes them (one
 // division) and the lanes that evaluate its samples later take them by readlane.
@@ -1034,10 +1035,10 @@ __device__ __forceinline__ void axis_line(float c1, float c2, int dim, int n, fl
         base = (float)(0.5 * (double)(c1 + c2) * (double)(dim - 1));
     }
 }
-__device__ __forceinline__ bool line_reaches(float base, float scale, int n, int target) {
+__device__ __forceinline__ bool line_reaches(float base, float scale, int n, int t0, int t1) {
     const float last = n > 1 ? base + (float)(n - 1) * scale : base;
     const float lo = floorf(fminf(base, last)), hi = ceilf(fmaxf(base, last));
-    return (float)target >= lo && (float)target <= hi;      // NaN -> false
+    return (float)t1 >= lo && (float)t0 <= hi;              // NaN -> false
 }
 __device__ __forceinline__ void line_sample(float base, float scale, int dim, int n, int s, int& lo,
                                             int& hi, float& frac, int& ok) {
@@ -1057,27 +1058,34 @@ __device__ __forceinline__ void line_sample(float base, float scale, int dim, in
 // first bin, records = its ph * pw * C elements): a pair's address is one scalar offset
 // (bin * C) next to the lane's fixed vector offset, and lanes beyond C carry an offset past
 // the records, so they read 0 without a branch.
-template <int POOL, int NQ>
+template <int POOL, int NQ, int CX>
 __device__ __forceinline__ void bwd_apply_candidate(
-    float4 (&acc)[NQ], __amdgpu_buffer_rsrc_t gbuf, __amdgpu_buffer_rsrc_t wbuf, int pw, int C,
+    float4 (&acc)[CX][NQ], __amdgpu_buffer_rsrc_t gbuf, __amdgpu_buffer_rsrc_t wbuf, int pw, int C,
     const uint32_t (&voff_g)[NQ], const uint32_t (&voff_w)[NQ], uint32_t ylo_m, uint32_t yhi_m,
-    uint32_t xlo_m, uint32_t xhi_m, float fr, int ylane0, int xlane0) {
+    const uint32_t (&xlo_m)[CX], const uint32_t (&xhi_m)[CX], float fr, int ylane0, int xlane0) {
     uint32_t ym = ylo_m | yhi_m;
-    const uint32_t xm_all = xlo_m | xhi_m;
+    uint32_t xm_all = 0u;
+#pragma unroll
+    for (int c = 0; c < CX; ++c) xm_all |= xlo_m[c] | xhi_m[c];
     if (ym == 0u || xm_all == 0u) return;
     while (ym != 0u) {
         const int sy = __ffs((int)ym) - 1;
         ym &= ym - 1u;
         const float ly = rlf(fr, ylane0 + sy);
-        const bool top = (ylo_m >> sy) & 1u, bot = (yhi_m >> sy) & 1u;
         const float wt = 1.0f - ly, wb = ly;
+        // sample columns per corner of this sample row: one scalar bit test per corner and pair
+        uint32_t tl_m[CX], tr_m[CX], bl_m[CX], br_m[CX];
+#pragma unroll
+        for (int c = 0; c < CX; ++c) {
+            tl_m[c] = (ylo_m >> sy) & 1u ? xlo_m[c] : 0u; tr_m[c] = (ylo_m >> sy) & 1u ? xhi_m[c] : 0u;
+            bl_m[c] = (yhi_m >> sy) & 1u ? xlo_m[c] : 0u; br_m[c] = (yhi_m >> sy) & 1u ? xhi_m[c] : 0u;
+        }
         const uint32_t rowbin = (uint32_t)((sy / POOL) * pw);
         uint32_t xm = xm_all;
         while (xm != 0u) {
             const int sx = __ffs((int)xm) - 1;
             xm &= xm - 1u;
             const float lx = rlf(fr, xlane0 + sx);
-            const bool left = (xlo_m >> sx) & 1u, right = (xhi_m >> sx) & 1u;
             const float wl = 1.0f - lx, wr = lx;
             const uint32_t k = (uint32_t)((sy % POOL) * POOL + (sx % POOL));
             const uint32_t soff = (rowbin + (uint32_t)(sx / POOL)) * (uint32_t)C;   // elements
@@ -1104,27 +1112,27 @@ __device__ __forceinline__ void bwd_apply_candidate(
             // corners in the order TL, TR, BL, BR; most pairs have one.  The empty asm
             // keeps each corner a (wave-uniform) branch: as selects, every pair would
             // pay for all four
-#define FRCNN_CORNER(cond, wy, wx)                                                               \
-            if (cond) {                                                                  \
+#define FRCNN_CORNER(M, wy, wx)                                                                  \
+            _Pragma("unroll") for (int c = 0; c < CX; ++c)                               \
+            if ((M[c] >> sx) & 1u) {                                                     \
                 asm volatile("");                                                        \
                 _Pragma("unroll") for (int u = 0; u < NQ; ++u) {                         \
                     const float4 g = gq[u];                                              \
                     const float4 d = make_float4(wy * g.x, wy * g.y, wy * g.z, wy * g.w); \
-                    acc[u].x += wx * d.x; acc[u].y += wx * d.y;                          \
-                    acc[u].z += wx * d.z; acc[u].w += wx * d.w;                          \
+                    acc[c][u].x += wx * d.x; acc[c][u].y += wx * d.y;                    \
+                    acc[c][u].z += wx * d.z; acc[c][u].w += wx * d.w;                    \
                 }                                                                        \
             }
-            FRCNN_CORNER(top && left, wt, wl)
-            FRCNN_CORNER(top && right, wt, wr)
-            FRCNN_CORNER(bot && left, wb, wl)
-            FRCNN_CORNER(bot && right, wb, wr)
+            FRCNN_CORNER(tl_m, wt, wl)
+            FRCNN_CORNER(tr_m, wt, wr)
+            FRCNN_CORNER(bl_m, wb, wl)
+            FRCNN_CORNER(br_m, wb, wr)
 #undef FRCNN_CORNER
         }
     }
-
 }
 
-template <int POOL, int NQ, int LW>
+template <int POOL, int NQ, int LW, int CX>
 __global__ void __launch_bounds__(64)
 roi_bwd_wave_kernel(const float* __restrict__ dY, const uint8_t* __restrict__ winner,
                     const float4* __restrict__ rois, int R, int r_begin, int r_end, int H, int W,
@@ -1138,9 +1146,13 @@ roi_bwd_wave_kernel(const float* __restrict__ dY, const uint8_t* __restrict__ wi
     // read the same dY bins at about the same time (all walk the RoIs in ascending order), so
     // an XCD takes a contiguous run of cells (a band of rows): gridDim.x is the cell count
     // rounded up to a multiple of 8, workgroup L is cell (L % 8) * gridDim.x / 8 + L / 8.
+    // A wave owns CX neighbouring cells of a row: a sample's left and right cell are neighbours,
+    // so with CX = 2 a fetched pair serves both of them (three pairs per two cells where
+    // one cell alone asks for two).
+    const int ncx = (W + CX - 1) / CX;
     const int cell = (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
-    if (cell >= H * W) return;
-    const int x = cell % W, y = cell / W, b = blockIdx.z;
+    if (cell >= H * ncx) return;
+    const int x = (cell % ncx) * CX, y = cell / ncx, b = blockIdx.z;
     const int lane = threadIdx.x;
     const int cq = (int)blockIdx.y * 64 * NQ + lane;         // blockIdx.y = slice of 256*NQ channels
     const int ph = ch / POOL, pw = cw / POOL;
@@ -1150,12 +1162,15 @@ roi_bwd_wave_kernel(const float* __restrict__ dY, const uint8_t* __restrict__ wi
     // when the next cell asks for them.  Later ranges continue the sums of the earlier ones
     // (same order of additions as one pass over all RoIs).
     float* dst = dfmap + (((size_t)b * H + y) * W + x) * C;
-    float4 acc[NQ];
+    float4 acc[CX][NQ];
+#pragma unroll
+    for (int c = 0; c < CX; ++c)
 #pragma unroll
     for (int u = 0; u < NQ; ++u) {
         const int c4 = cq + 64 * u;
-        acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r_begin > 0 && c4 < C4) acc[u] = *reinterpret_cast<const float4*>(dst + c4 * 4);
+        acc[c][u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r_begin > 0 && c4 < C4 && x + c < W)
+            acc[c][u] = *reinterpret_cast<const float4*>(dst + (size_t)c * C + c4 * 4);
     }
     // this lane's byte offsets inside a bin; past every record for channels beyond C
     uint32_t voff_g[NQ], voff_w[NQ];
@@ -1182,7 +1197,8 @@ roi_bwd_wave_kernel(const float* __restrict__ dY, const uint8_t* __restrict__ wi
             const float4 box = rb[r];
             axis_line(box.x, box.z, H, ch, line.x, line.z);
             axis_line(box.y, box.w, W, cw, line.y, line.w);
-            cand = line_reaches(line.x, line.z, ch, y) && line_reaches(line.y, line.w, cw, x);
+            cand = line_reaches(line.x, line.z, ch, y, y) &&
+                   line_reaches(line.y, line.w, cw, x, min(x + CX, W) - 1);
         }
         unsigned long long m = __ballot(cand);
 #pragma unroll 1
@@ -1210,6 +1226,9 @@ roi_bwd_wave_kernel(const float* __restrict__ dY, const uint8_t* __restrict__ wi
             const bool v = act && ok;
             const unsigned long long mlo = __ballot(v && lo == target);
             const unsigned long long mhi = __ballot(v && hi == target);
+            // the second cell's column (x + 1 < W whenever a sample has it as floor or ceil)
+            const unsigned long long mlo1 = CX > 1 ? __ballot(v && lo == target + 1) : 0ull;
+            const unsigned long long mhi1 = CX > 1 ? __ballot(v && hi == target + 1) : 0ull;
 #pragma unroll 1
             for (int t = 0; t < nc; ++t) {
             const int sh = t * 2 * LW;                        // first lane of candidate t
@@ -1217,24 +1236,34 @@ roi_bwd_wave_kernel(const float* __restrict__ dY, const uint8_t* __restrict__ wi
             static_assert(NC <= 2, "candidate t is picked from lc[0] / lc[1]");
             const uint32_t ylo_m = (uint32_t)(mlo >> sh) & FIELD;
             const uint32_t yhi_m = (uint32_t)(mhi >> sh) & FIELD;
-            const uint32_t xlo_m = (uint32_t)(mlo >> (sh + LW)) & FIELD;
-            const uint32_t xhi_m = (uint32_t)(mhi >> (sh + LW)) & FIELD;
-            if (((ylo_m | yhi_m) == 0u) || ((xlo_m | xhi_m) == 0u)) continue;
+            uint32_t xlo_m[CX], xhi_m[CX];
+            xlo_m[0] = (uint32_t)(mlo >> (sh + LW)) & FIELD;
+            xhi_m[0] = (uint32_t)(mhi >> (sh + LW)) & FIELD;
+            uint32_t xany = xlo_m[0] | xhi_m[0];
+            if (CX > 1) {
+                xlo_m[CX - 1] = (uint32_t)(mlo1 >> (sh + LW)) & FIELD;
+                xhi_m[CX - 1] = (uint32_t)(mhi1 >> (sh + LW)) & FIELD;
+                xany |= xlo_m[CX - 1] | xhi_m[CX - 1];
+            }
+            static_assert(CX <= 2, "one extra pair of ballots");
+            if (((ylo_m | yhi_m) == 0u) || xany == 0u) continue;
             const size_t rbase = ((size_t)b * R + (r0 + l)) * (size_t)roi_elems;
             const __amdgpu_buffer_rsrc_t gbuf = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float*>(dY + rbase), 0, roi_elems * 4u, 0x00020000);
             const __amdgpu_buffer_rsrc_t wbuf = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<uint8_t*>(POOL > 1 ? winner + rbase : nullptr), 0, POOL > 1 ? roi_elems : 0u,
                 0x00020000);
-            bwd_apply_candidate<POOL, NQ>(acc, gbuf, wbuf, pw, C, voff_g, voff_w, ylo_m, yhi_m,
+            bwd_apply_candidate<POOL, NQ, CX>(acc, gbuf, wbuf, pw, C, voff_g, voff_w, ylo_m, yhi_m,
                                           xlo_m, xhi_m, fr, sh, sh + LW);
             }
         }
     }
 #pragma unroll
+    for (int c = 0; c < CX; ++c)
+#pragma unroll
     for (int u = 0; u < NQ; ++u) {
         const int c4 = cq + 64 * u;
-        if (c4 < C4) *reinterpret_cast<float4*>(dst + c4 * 4) = acc[u];
+        if (c4 < C4 && x + c < W) *reinterpret_cast<float4*>(dst + (size_t)c * C + c4 * 4) = acc[c][u];
     }
 }
 
@@ -1331,8 +1360,15 @@ extern "C" int frcnn_roi_crop_pool_bwd(const float* dY, const uint8_t* winner, c
         const int nqk = nq <= 1 ? 1 : nq <= 2 ? 2 : nq <= 4 ? 4 : 8;
         const int nsl = (C / 4 + 64 * nqk - 1) / (64 * nqk);
         const bool pack2 = crop_h <= 16 && crop_w <= 16;      // two candidates per evaluation
-        const dim3 cgrid((unsigned)(((long long)H * W + 7) / 8 * 8), (unsigned)nsl, (unsigned)B);
-        int chunk = 512;                 // RoIs per launch (a multiple of 64): 241-245 us per image at 256-512, 281 in one launch (B = 64)
+        // cells per wave: two neighbours of a row share the pairs they fetch (B = 64: 12.4 ms
+        // against 14.3 ms with one cell per wave; B = 8: 2.09 against 2.14)
+        int cx = 2;
+        if (const char* e = getenv("FRCNN_BWD_CX")) cx = atoi(e) == 1 ? 1 : 2;
+        const dim3 cgrid((unsigned)(((long long)H * ((W + cx - 1) / cx) + 7) / 8 * 8), (unsigned)nsl,
+                         (unsigned)B);
+        // RoIs per launch (a multiple of 64).  B = 64: 194 us per image at 256-512, 197 at 1,024;
+        // B = 8 (too few waves to fill the chip twice): 271 / 261 / 260 / 253 at 256 / 512 / 1,024 / all
+        int chunk = B >= 32 ? 512 : R;
         if (const char* e = getenv("FRCNN_BWD_CHUNK")) chunk = atoi(e);
         if (chunk <= 0 || chunk > R) chunk = R;
         chunk = (chunk + 63) / 64 * 64;
@@ -1340,11 +1376,17 @@ extern "C" int frcnn_roi_crop_pool_bwd(const float* dY, const uint8_t* winner, c
     do {                                                                                         \
         for (int rb0 = 0; rb0 < R; rb0 += chunk) {                                               \
             const int re = rb0 + chunk < R ? rb0 + chunk : R;                                    \
-            if (pack2)                                                                           \
-                FRCNN_LAUNCH((roi_bwd_wave_kernel<P, Q, 16>), cgrid, dim3(64), 0, st, dY, winner, \
+            if (pack2 && cx == 2)                                                                \
+                FRCNN_LAUNCH((roi_bwd_wave_kernel<P, Q, 16, 2>), cgrid, dim3(64), 0, st, dY, winner, \
+                             rb, R, rb0, re, H, W, C, crop_h, crop_w, dfmap);                    \
+            else if (pack2)                                                                      \
+                FRCNN_LAUNCH((roi_bwd_wave_kernel<P, Q, 16, 1>), cgrid, dim3(64), 0, st, dY, winner, \
+                             rb, R, rb0, re, H, W, C, crop_h, crop_w, dfmap);                    \
+            else if (cx == 2)                                                                    \
+                FRCNN_LAUNCH((roi_bwd_wave_kernel<P, Q, 32, 2>), cgrid, dim3(64), 0, st, dY, winner, \
                              rb, R, rb0, re, H, W, C, crop_h, crop_w, dfmap);                    \
             else                                                                                 \
-                FRCNN_LAUNCH((roi_bwd_wave_kernel<P, Q, 32>), cgrid, dim3(64), 0, st, dY, winner, \
+                FRCNN_LAUNCH((roi_bwd_wave_kernel<P, Q, 32, 1>), cgrid, dim3(64), 0, st, dY, winner, \
                              rb, R, rb0, re, H, W, C, crop_h, crop_w, dfmap);                    \
         }                                                                                        \
     } while (0)
