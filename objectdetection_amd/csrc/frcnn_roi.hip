@@ -1136,25 +1136,40 @@ template <int POOL, int NQ, int LW, int CX>
 __global__ void __launch_bounds__(64)
 roi_bwd_wave_kernel(const float* __restrict__ dY, const uint8_t* __restrict__ winner,
                     const float4* __restrict__ rois, int R, int r_begin, int r_end, int H, int W,
-                    int C, int ch, int cw, float* __restrict__ dfmap) {
+                    int C, int ch, int cw, int nitem, int nsl, float* __restrict__ dfmap) {
     // The sample geometry of a candidate takes LW lanes per axis (crop <= LW), so one
     // evaluation serves NC = 32 / LW candidates: lanes [2*LW*t, 2*LW*t + LW) hold the sample
     // rows of candidate t, the next LW lanes its sample columns.
     constexpr int NC = 32 / LW;
     constexpr uint32_t FIELD = LW == 32 ? 0xFFFFFFFFu : ((1u << (LW & 31)) - 1u);
-    // Workgroups go to the 8 XCDs round-robin, each XCD with its own L2.  Neighbouring cells
-    // read the same dY bins at about the same time (all walk the RoIs in ascending order), so
-    // an XCD takes a contiguous run of cells (a band of rows): gridDim.x is the cell count
-    // rounded up to a multiple of 8, workgroup L is cell (L % 8) * gridDim.x / 8 + L / 8.
     // A wave owns CX neighbouring cells of a row: a sample's left and right cell are neighbours,
     // so with CX = 2 a fetched pair serves both of them (three pairs per two cells where
     // one cell alone asks for two).
     const int ncx = (W + CX - 1) / CX;
-    const int cell = (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
-    if (cell >= H * ncx) return;
-    const int x = (cell % ncx) * CX, y = cell / ncx, b = blockIdx.z;
+    // Workgroup n runs on XCD n % 8, each XCD with its own L2.  The cells of one (image, channel
+    // slice) all go to ONE XCD: a bin of pooled gradients is asked for by the handful of waves
+    // around its samples, and only that XCD's L2 ever holds it (with an image spread over the
+    // XCDs as bands of rows, the bins along the band edges went through two L2s, and every L2
+    // streamed a share of every image in flight).
+    int cell, b, slice;
+    {
+        const int ncell = H * ncx, n = (int)blockIdx.x, full = nitem & ~7;
+        int item;
+        if (n < full * ncell) {
+            const int slot = n >> 3;
+            item = 8 * (slot / ncell) + (n & 7);
+            cell = slot % ncell;
+        } else {
+            const int m = n - full * ncell;
+            item = full + m / ncell;
+            cell = m % ncell;
+        }
+        b = item / nsl;
+        slice = item - b * nsl;
+    }
+    const int x = (cell % ncx) * CX, y = cell / ncx;
     const int lane = threadIdx.x;
-    const int cq = (int)blockIdx.y * 64 * NQ + lane;         // blockIdx.y = slice of 256*NQ channels
+    const int cq = slice * 64 * NQ + lane;                   // a slice = 256*NQ channels
     const int ph = ch / POOL, pw = cw / POOL;
     const int C4 = C >> 2;
     // RoIs [r_begin, r_end) of every image: a launch per range keeps the cells of a band within
@@ -1364,10 +1379,13 @@ extern "C" int frcnn_roi_crop_pool_bwd(const float* dY, const uint8_t* winner, c
         // against 14.3 ms with one cell per wave; B = 8: 2.09 against 2.14)
         int cx = 2;
         if (const char* e = getenv("FRCNN_BWD_CX")) cx = atoi(e) == 1 ? 1 : 2;
-        const dim3 cgrid((unsigned)(((long long)H * ((W + cx - 1) / cx) + 7) / 8 * 8), (unsigned)nsl,
-                         (unsigned)B);
-        // RoIs per launch (a multiple of 64).  B = 64: 194 us per image at 256-512, 197 at 1,024;
-        // B = 8 (too few waves to fill the chip twice): 271 / 261 / 260 / 253 at 256 / 512 / 1,024 / all
+        const long long nwave = (long long)H * ((W + cx - 1) / cx) * B * nsl;
+        if (nwave > 0x7FFFFFF0ll) return FRCNN_E_UNSUPPORTED;
+        const dim3 cgrid((unsigned)nwave);
+        // RoIs per launch (a multiple of 64): a launch per range keeps the waves of an image
+        // within a few hundred RoIs of each other, so more of the bins they share are still in
+        // the L2 when the next wave asks.  B = 64: 11.1 ms at 512, 11.3 at 256, 12.2 in one
+        // launch; B = 8 has too few waves to fill the chip twice and is best in one launch.
         int chunk = B >= 32 ? 512 : R;
         if (const char* e = getenv("FRCNN_BWD_CHUNK")) chunk = atoi(e);
         if (chunk <= 0 || chunk > R) chunk = R;
@@ -1378,16 +1396,16 @@ extern "C" int frcnn_roi_crop_pool_bwd(const float* dY, const uint8_t* winner, c
             const int re = rb0 + chunk < R ? rb0 + chunk : R;                                    \
             if (pack2 && cx == 2)                                                                \
                 FRCNN_LAUNCH((roi_bwd_wave_kernel<P, Q, 16, 2>), cgrid, dim3(64), 0, st, dY, winner, \
-                             rb, R, rb0, re, H, W, C, crop_h, crop_w, dfmap);                    \
+                             rb, R, rb0, re, H, W, C, crop_h, crop_w, B * nsl, nsl, dfmap);      \
             else if (pack2)                                                                      \
                 FRCNN_LAUNCH((roi_bwd_wave_kernel<P, Q, 16, 1>), cgrid, dim3(64), 0, st, dY, winner, \
-                             rb, R, rb0, re, H, W, C, crop_h, crop_w, dfmap);                    \
+                             rb, R, rb0, re, H, W, C, crop_h, crop_w, B * nsl, nsl, dfmap);      \
             else if (cx == 2)                                                                    \
                 FRCNN_LAUNCH((roi_bwd_wave_kernel<P, Q, 32, 2>), cgrid, dim3(64), 0, st, dY, winner, \
-                             rb, R, rb0, re, H, W, C, crop_h, crop_w, dfmap);                    \
+                             rb, R, rb0, re, H, W, C, crop_h, crop_w, B * nsl, nsl, dfmap);      \
             else                                                                                 \
                 FRCNN_LAUNCH((roi_bwd_wave_kernel<P, Q, 32, 1>), cgrid, dim3(64), 0, st, dY, winner, \
-                             rb, R, rb0, re, H, W, C, crop_h, crop_w, dfmap);                    \
+                             rb, R, rb0, re, H, W, C, crop_h, crop_w, B * nsl, nsl, dfmap);      \
         }                                                                                        \
     } while (0)
 #define FRCNN_BWD_P(P)                                                                           \
