@@ -2,6 +2,7 @@
 // sort, fused box decode) and greedy NMS (wave-ballot bitmask kernel followed
 // by a one-wave scan per image).  gfx950, wave64.  -ffp-contract=off.
 #include "frcnn_common.h"
+#include <cstdlib>
 #include <atomic>
 
 namespace frcnn {
@@ -75,11 +76,6 @@ constexpr int NMS_CW = 16;                      // column blocks per chunk
                                                 // beside a kernel whose waves hold 128 each such a
                                                 // wave waits for two of them to end on one SIMD
 #endif
-#ifndef NMS_MASK_WAVES
-#define NMS_MASK_WAVES 1                        // row tiles (waves) per mask workgroup: one-wave
-                                                // workgroups also get wave slots while another
-                                                // stream's kernel fills the chip
-#endif
 constexpr int NMS_COLS = NMS_CW * 64;           // columns per chunk
 
 struct NBox { float y0, x0, y1, x1, area, t; };          // t = thr_lo * area
@@ -138,61 +134,75 @@ __device__ __forceinline__ unsigned long long mask_tile(const NBox& a, float c1,
     return mine;
 }
 
-// grid (ceil((KT + NMS_CW) / NMS_MASK_WAVES), NMS_CW, B), NMS_MASK_WAVES waves: wave = one row
-// tile.  Capped at 64 VGPRs: two such waves fit the registers one 128-VGPR wave of a kernel
-// running beside it frees.
+// grid (NMS_CW * gk + NMS_TRI, 1, B), one wave per workgroup (one-wave workgroups also get
+// wave slots while another stream's kernel fills the chip).  The first NMS_CW * gk workgroups
+// take the KEPT row tiles: gk per column block, which share the block's tiles [0,nkt) with
+// stride gk (how many boxes are kept is only known on the device).  The other NMS_TRI take the
+// in-chunk row blocks, one tile each: column block jbl has the row blocks 0..jbl, and blocks
+// p and NMS_CW-1-p together always have NMS_CW+1, so the triangle folds into NMS_CW/2 rows of
+// NMS_CW+1 workgroups with none left empty.  (One workgroup per conceivable tile -- 48 per
+// column block -- left most of them empty whenever few boxes are kept, and an empty workgroup
+// still holds a wave slot for the two dependent loads that tell it so.)
+// Capped at 64 VGPRs: two such waves fit the registers one 128-VGPR wave of a kernel running
+// beside it frees.
 // maskK [B][KT][NMS_COLS], maskD [B][NMS_CW][NMS_COLS].
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8)))
-nms_mask_kernel(const float4* __restrict__ boxes, int K, int cb0, int KT, int post_n, float thr,
-                float c1, float thr_lo, const int* __restrict__ done,
+constexpr int NMS_TRI = (NMS_CW / 2) * (NMS_CW + 1);
+static_assert(NMS_CW % 2 == 0, "the triangle folds in pairs of column blocks");
+
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8)))
+nms_mask_kernel(const float4* __restrict__ boxes, int K, int cb0, int KT, int post_n, int gk,
+                float thr, float c1, float thr_lo, const int* __restrict__ done,
                 const int* __restrict__ count_g, const int32_t* __restrict__ keep_idx,
                 unsigned long long* __restrict__ maskK, unsigned long long* __restrict__ maskD) {
     const int b = blockIdx.z;
-    const int jbl = blockIdx.y;                         // column block inside the chunk
-    const int jb = cb0 + jbl;
     // the first chunk starts from an empty keep list and never reads count / done: the
     // workspace needs no clearing between calls
-    if (jb * 64 >= K || (cb0 != 0 && done[b])) return;  // block-uniform
+    if (cb0 != 0 && done[b]) return;
+    int jbl, part = 0, ibl = -1;                        // column block; kept role: part, else row block
+    {
+        const int n = (int)blockIdx.x;
+        if (n < NMS_CW * gk) {
+            jbl = n / gk;
+            part = n - jbl * gk;
+        } else {
+            const int t = n - NMS_CW * gk, p = t / (NMS_CW + 1), q = t - p * (NMS_CW + 1);
+            if (q <= p) { jbl = p; ibl = q; }
+            else { jbl = NMS_CW - 1 - p; ibl = q - p - 1; }
+        }
+    }
+    const int jb = cb0 + jbl;
+    if (jb * 64 >= K) return;
     const int count = cb0 != 0 ? count_g[b] : 0;        // boxes kept before this chunk
     const int nkt = (count + 63) >> 6;
-    const int nw = blockDim.x >> 6;                     // row tiles (waves) per workgroup
-    const int rt0 = blockIdx.x * nw;
-    // tiles rt0..rt0+nw-1: kept tiles are [0,nkt), in-chunk row blocks are KT + [0,jbl]
-    if (rt0 >= nkt && rt0 + nw - 1 < KT) return;        // only empty kept tiles
-    if (rt0 > KT + jbl) return;                         // only tiles right of the diagonal
+    if (ibl < 0 && part >= nkt) return;                 // no kept tile for this workgroup
+    const int lane = lane_id();
     __shared__ NBox s_col[64];
     const float4* bx = boxes + (size_t)b * K;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (threadIdx.x < 64) {
-        const int j = jb * 64 + threadIdx.x;
-        s_col[threadIdx.x] = norm_box(j < K ? bx[j] : zero4, thr_lo);
+    {
+        const int j = jb * 64 + lane;
+        s_col[lane] = norm_box(j < K ? bx[j] : zero4, thr_lo);
     }
-    __syncthreads();
-    const int rt = rt0 + wave_id();
-    const int lane = lane_id();
-    float4 rowbox = zero4;
-    bool diag = false;
-    unsigned long long* dst;
-    if (rt < KT) {
-        if (rt >= nkt) return;                          // wave-uniform
-        const int slot = rt * 64 + lane;
-        if (slot < count) rowbox = bx[keep_idx[(size_t)b * post_n + slot]];
-        dst = maskK + ((size_t)b * KT + rt) * NMS_COLS;
-    } else {
-        const int ibl = rt - KT;
-        if (ibl > jbl) return;                          // wave-uniform
+    __builtin_amdgcn_wave_barrier();                    // one wave: its LDS writes are in order
+    if (ibl >= 0) {
         const int i = (cb0 + ibl) * 64 + lane;
-        if (i < K) rowbox = bx[i];
-        diag = (ibl == jbl);
-        dst = maskD + ((size_t)b * NMS_CW + ibl) * NMS_COLS;
+        const NBox a = norm_box(i < K ? bx[i] : zero4, thr_lo);
+        // a tiny row area could underflow the filter's products: +inf makes the filter pass
+        // whenever the boxes intersect, and the exact test decides
+        const float c1l = a.area < NMS_TINY_AREA ? __builtin_inff() : c1;
+        const unsigned long long mine = ibl == jbl ? mask_tile<true>(a, c1l, s_col, thr, lane)
+                                                   : mask_tile<false>(a, c1l, s_col, thr, lane);
+        maskD[((size_t)b * NMS_CW + ibl) * NMS_COLS + jbl * 64 + lane] = mine;
+        return;
     }
-    const NBox a = norm_box(rowbox, thr_lo);
-    // a tiny row area could underflow the filter's products: +inf makes the filter pass
-    // whenever the boxes intersect, and the exact test decides
-    const float c1l = a.area < NMS_TINY_AREA ? __builtin_inff() : c1;
-    const unsigned long long mine = diag ? mask_tile<true>(a, c1l, s_col, thr, lane)
-                                         : mask_tile<false>(a, c1l, s_col, thr, lane);
-    dst[jbl * 64 + lane] = mine;
+#pragma unroll 1
+    for (int rt = part; rt < nkt; rt += gk) {
+        const int slot = rt * 64 + lane;
+        const NBox a = norm_box(slot < count ? bx[keep_idx[(size_t)b * post_n + slot]] : zero4, thr_lo);
+        const float c1l = a.area < NMS_TINY_AREA ? __builtin_inff() : c1;
+        const unsigned long long mine = mask_tile<false>(a, c1l, s_col, thr, lane);
+        maskK[((size_t)b * KT + rt) * NMS_COLS + jbl * 64 + lane] = mine;
+    }
 }
 
 // One workgroup (NMS_SCAN_WAVES waves) per image walks the chunk's column blocks in order.
@@ -384,7 +394,7 @@ static int nms_launch(const float* boxes, int B, int K, float iou_threshold, int
                       hipStream_t st) {
     const int CB = (K + 63) / 64;
     const int KT = (post_n + 63) / 64;
-    if (B > 65535 || (KT + NMS_CW + 3) / 4 > 0x7FFFFFFF) return FRCNN_E_UNSUPPORTED;
+    if (B > 65535) return FRCNN_E_UNSUPPORTED;
     unsigned long long* maskK = reinterpret_cast<unsigned long long*>(ws);
     ws += nms_maskk_bytes(B, post_n);
     unsigned long long* maskD = reinterpret_cast<unsigned long long*>(ws);
@@ -396,12 +406,16 @@ static int nms_launch(const float* boxes, int B, int K, float iou_threshold, int
     // filter constants: iou > thr  =>  inter*(1+thr) > thr*(1-4e-6)*(area_i+area_j)
     const float c1 = 1.0f + iou_threshold;
     const float thr_lo = iou_threshold * 0.999996f;
+    // workgroups per column block for the kept row tiles: one per tile with few images (every
+    // tile in parallel), fewer -- each taking several tiles in turn -- with many
+    int gk = (16384 + NMS_CW * B - 1) / (NMS_CW * B);
+    if (const char* e = getenv("FRCNN_NMS_GK")) gk = atoi(e);
+    gk = gk < 1 ? 1 : gk > KT ? KT : gk;
     for (int cb0 = 0; cb0 < CB; cb0 += NMS_CW) {
         const int last = cb0 + NMS_CW >= CB;
-        FRCNN_LAUNCH(nms_mask_kernel, dim3((KT + NMS_CW + NMS_MASK_WAVES - 1) / NMS_MASK_WAVES, NMS_CW, B),
-                     dim3(64 * NMS_MASK_WAVES), 0, st,
-                     reinterpret_cast<const float4*>(boxes), K, cb0, KT, post_n, iou_threshold, c1,
-                     thr_lo, done, count, keep_idx, maskK, maskD);
+        FRCNN_LAUNCH(nms_mask_kernel, dim3(NMS_CW * gk + NMS_TRI, 1, B), dim3(64), 0, st,
+                     reinterpret_cast<const float4*>(boxes), K, cb0, KT, post_n, gk, iou_threshold,
+                     c1, thr_lo, done, count, keep_idx, maskK, maskD);
         FRCNN_LAUNCH(nms_scan_kernel, dim3(B), dim3(64 * NMS_SCAN_WAVES), 0, st,
                      reinterpret_cast<const float4*>(boxes), maskK, maskD, K, cb0, KT, post_n, last,
                      count, done, keep_idx, reinterpret_cast<float4*>(proposed), keep_pos,
