@@ -134,6 +134,34 @@ __device__ __forceinline__ unsigned long long mask_tile(const NBox& a, float c1,
     return mine;
 }
 
+// The same tile when all that matters is WHETHER some row suppresses the column (the rows are
+// kept boxes): bit c of the result.  The ballot words never leave the scalar registers.
+__device__ __forceinline__ unsigned long long mask_tile_any(const NBox& a, float c1, const NBox* cols,
+                                                            float thr) {
+    unsigned long long dead = 0ull;
+#pragma unroll 1
+    for (int c0 = 0; c0 < 64; c0 += 8) {
+        NBox grp[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) grp[u] = cols[c0 + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const NBox cb = grp[u];
+            const float iy0 = vmax2(a.y0, cb.y0), ix0 = vmax2(a.x0, cb.x0);
+            const float iy1 = vmin2(a.y1, cb.y1), ix1 = vmin2(a.x1, cb.x1);
+            const float fil = vmax2(iy1 - iy0, 0.0f) * (ix1 - ix0);
+            unsigned long long w = __ballot(__builtin_fmaf(fil, c1, -cb.t) > a.t);
+            if (w != 0ull) {                                                // uniform
+                const float inter = vmax2(iy1 - iy0, 0.0f) * vmax2(ix1 - ix0, 0.0f);
+                const float u2 = a.area + cb.area - inter;
+                w = __ballot((a.area > 0.0f) && (cb.area > 0.0f) && (inter / u2 > thr));
+                if (w != 0ull) dead |= 1ull << (c0 + u);
+            }
+        }
+    }
+    return dead;
+}
+
 // grid (NMS_CW * gk + NMS_TRI, 1, B), one wave per workgroup (one-wave workgroups also get
 // wave slots while another stream's kernel fills the chip).  The first NMS_CW * gk workgroups
 // take the KEPT row tiles: gk per column block, which share the block's tiles [0,nkt) with
@@ -145,7 +173,8 @@ __device__ __forceinline__ unsigned long long mask_tile(const NBox& a, float c1,
 // still holds a wave slot for the two dependent loads that tell it so.)
 // Capped at 64 VGPRs: two such waves fit the registers one 128-VGPR wave of a kernel running
 // beside it frees.
-// maskK [B][KT][NMS_COLS], maskD [B][NMS_CW][NMS_COLS].
+// maskK [B][NMS_CW][KT]: ONE word per (column block, kept tile), bit c = the tile suppresses
+// column c; maskD [B][NMS_CW][NMS_COLS]: a word per column (bit r = row r suppresses it).
 constexpr int NMS_TRI = (NMS_CW / 2) * (NMS_CW + 1);
 static_assert(NMS_CW % 2 == 0, "the triangle folds in pairs of column blocks");
 
@@ -200,8 +229,8 @@ nms_mask_kernel(const float4* __restrict__ boxes, int K, int cb0, int KT, int po
         const int slot = rt * 64 + lane;
         const NBox a = norm_box(slot < count ? bx[keep_idx[(size_t)b * post_n + slot]] : zero4, thr_lo);
         const float c1l = a.area < NMS_TINY_AREA ? __builtin_inff() : c1;
-        const unsigned long long mine = mask_tile<false>(a, c1l, s_col, thr, lane);
-        maskK[((size_t)b * KT + rt) * NMS_COLS + jbl * 64 + lane] = mine;
+        const unsigned long long dead = mask_tile_any(a, c1l, s_col, thr);
+        if (lane == 0) maskK[((size_t)b * NMS_CW + jbl) * KT + rt] = dead;
     }
 }
 
@@ -219,7 +248,7 @@ nms_scan_kernel(const float4* __restrict__ boxes, const unsigned long long* __re
     if (cb0 != 0 && done[b]) return;                    // block-uniform
     const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
     const float4* bx = boxes + (size_t)b * K;
-    const unsigned long long* mk = maskK + (size_t)b * KT * NMS_COLS;
+    const unsigned long long* mk = maskK + (size_t)b * NMS_CW * KT;
     const unsigned long long* md = maskD + (size_t)b * NMS_CW * NMS_COLS;
     float4* prop = proposed + (size_t)b * post_n;
     int32_t* kidx = keep_idx + (size_t)b * post_n;
@@ -235,22 +264,23 @@ nms_scan_kernel(const float4* __restrict__ boxes, const unsigned long long* __re
     // sees no load latency.  A wave owns kept tiles wave, wave+SW, ... and
     // in-chunk rows wave, wave+SW, ...
     constexpr int SW = NMS_SCAN_WAVES;
-    // the kept-tile words stay raw until the block is resolved (an OR here would wait for
-    // the loads inside the prefetch); a wave holds at most KMAX of them in registers, the
-    // rest (post_n > 64 * SW * KMAX) are folded in at once
+    // a wave holds at most KMAX kept-tile words (wave-uniform: one word per tile and column
+    // block) raw until the block is resolved (an OR here would wait for the loads inside the
+    // prefetch); the rest (post_n > 64 * SW * KMAX) are folded in at once
     constexpr int KMAX = 8;
     struct Pre { unsigned long long hk[KMAX], more, diag, mdw[NMS_CW / SW]; float4 box; };
     auto prefetch = [&](int jbl) {
         Pre p;
         const int col = jbl * 64 + lane;
         p.diag = wave == 0 ? md[(size_t)jbl * NMS_COLS + col] : 0ull;
+        const unsigned long long* mkb = mk + (size_t)jbl * KT;
 #pragma unroll
         for (int t = 0; t < KMAX; ++t) {
             const int kt = wave + SW * t;
-            p.hk[t] = kt < nkt ? mk[(size_t)kt * NMS_COLS + col] : 0ull;
+            p.hk[t] = kt < nkt ? mkb[kt] : 0ull;
         }
         p.more = 0ull;
-        for (int kt = wave + SW * KMAX; kt < nkt; kt += SW) p.more |= mk[(size_t)kt * NMS_COLS + col];
+        for (int kt = wave + SW * KMAX; kt < nkt; kt += SW) p.more |= mkb[kt];
 #pragma unroll
         for (int t = 0; t < NMS_CW / SW; ++t) {
             const int ibl = wave + SW * t;
@@ -277,16 +307,17 @@ nms_scan_kernel(const float4* __restrict__ boxes, const unsigned long long* __re
         if (jbl + 1 < nblk) nxt = prefetch(jbl + 1);    // block-uniform, one block ahead
 #endif
         const int j0 = (cb0 + jbl) * 64;
-        unsigned long long hit = cur.more;
+        unsigned long long by_kept = cur.more;          // columns a kept tile of this wave suppresses
 #pragma unroll
-        for (int t = 0; t < KMAX; ++t) hit |= cur.hk[t];
+        for (int t = 0; t < KMAX; ++t) by_kept |= cur.hk[t];
+        unsigned long long hit = 0ull;
 #pragma unroll
         for (int t = 0; t < NMS_CW / SW; ++t) {
             const int ibl = wave + SW * t;
             if (ibl < jbl) hit |= cur.mdw[t] & keptw[ibl];
         }
         const unsigned long long diag = cur.diag;
-        const unsigned long long dead = __ballot(hit != 0ull);
+        const unsigned long long dead = uniform64(by_kept) | __ballot(hit != 0ull);
         if (lane == 0) deadw[wave] = dead;
         __syncthreads();
         if (wave == 0) {
