@@ -144,7 +144,7 @@ int frcnn_topk_sort(const float* scores, int B, int N, int K,
  * keep_pos [B,post_n] i32 = kept positions in 0..K-1, -1 padded (may be NULL);
  * keep_count [B] i32 (may be NULL).
  * workspace: frcnn_nms_workspace_bytes(B,K,post_n) bytes, 256-byte aligned
- * (about 8 KB x (post_n/64 + 16) + 4 x post_n bytes per image; independent of K); its
+ * (about 256 KB + 6 x post_n bytes per image; independent of K); its
  * contents on entry do not matter (nothing has to be cleared between calls).  Only kernel
  * launches are issued, so the call can be recorded into a HIP graph. */
 size_t frcnn_nms_workspace_bytes(int B, int K, int post_n);
@@ -158,7 +158,7 @@ int frcnn_nms(const float* boxes, int B, int K, float iou_threshold, int post_n,
  * index list and the counters live in a device array built into the library
  * (FRCNN_NMS_STATIC_BYTES per GPU, held until the process ends).  The call allocates and frees
  * nothing.  Returns FRCNN_E_STATIC_LIMIT when frcnn_nms_workspace_bytes(B,K,post_n) exceeds
- * FRCNN_NMS_STATIC_BYTES (e.g. post_n = 2000: up to 42 images per call; the need does not
+ * FRCNN_NMS_STATIC_BYTES (e.g. post_n = 2000: up to 61 images per call; the need does not
  * depend on K).  Nothing has to be cleared between calls (the first chunk of a call never reads
  * the array).  All calls on one GPU share the array: calls that overlap on one GPU (two
  * streams, two threads) race -- order them, or use frcnn_nms with a workspace per stream.

@@ -58,13 +58,16 @@ topk_kernel(const float* __restrict__ scores, int N, int K, int n_pad,
 //   (b) the chunk's own candidates (upper triangle of the chunk's tiles),
 // one wave per 64x64 tile: lane = row box, the 64 column boxes in LDS, the wave
 // ballot of the suppress predicate = the column's mask word (bit r = row r of
-// the tile suppresses the column).  The scan kernel (one workgroup per image)
-// then walks the chunk's column blocks: a column is dead if any kept-tile word
-// is non-zero or an in-chunk word meets that block's keep bits; the block's own
+// the tile suppresses the column).  Of a kept tile only one word per column block
+// is stored (bit c = some row suppresses column c); the in-chunk tiles keep a word
+// per column, and as they depend on the boxes only, those of chunk c+1 are computed
+// beside the scan of chunk c.  The scan (one workgroup per image)
+// then walks the chunk's column blocks: a column is dead if a kept tile's word
+// has its bit or an in-chunk word meets that block's keep bits; the block's own
 // triangle is resolved serially by one wave.  An image that has post_n boxes
 // raises `done` and every later block of it returns at once.
 // Pair tests executed: (kept so far) x (columns examined) + the chunk triangles,
-// instead of K^2/2; mask storage is two small per-image buffers reused by
+// instead of K^2/2; mask storage is three small per-image buffers reused by
 // every chunk.
 constexpr int NMS_CW = 16;                      // column blocks per chunk
 #ifndef NMS_SCAN_WAVES
@@ -162,22 +165,52 @@ __device__ __forceinline__ unsigned long long mask_tile_any(const NBox& a, float
     return dead;
 }
 
-// grid (NMS_CW * gk + NMS_TRI, 1, B), one wave per workgroup (one-wave workgroups also get
-// wave slots while another stream's kernel fills the chip).  The first NMS_CW * gk workgroups
-// take the KEPT row tiles: gk per column block, which share the block's tiles [0,nkt) with
-// stride gk (how many boxes are kept is only known on the device).  The other NMS_TRI take the
-// in-chunk row blocks, one tile each: column block jbl has the row blocks 0..jbl, and blocks
-// p and NMS_CW-1-p together always have NMS_CW+1, so the triangle folds into NMS_CW/2 rows of
-// NMS_CW+1 workgroups with none left empty.  (One workgroup per conceivable tile -- 48 per
-// column block -- left most of them empty whenever few boxes are kept, and an empty workgroup
-// still holds a wave slot for the two dependent loads that tell it so.)
-// Capped at 64 VGPRs: two such waves fit the registers one 128-VGPR wave of a kernel running
-// beside it frees.
-// maskK [B][NMS_CW][KT]: ONE word per (column block, kept tile), bit c = the tile suppresses
-// column c; maskD [B][NMS_CW][NMS_COLS]: a word per column (bit r = row r suppresses it).
+// The in-chunk tiles of a chunk: column block jbl has the row blocks 0..jbl, and blocks p and
+// NMS_CW-1-p together always have NMS_CW+1, so the triangle folds into NMS_CW/2 rows of
+// NMS_CW+1 tiles, t = 0 .. NMS_TRI-1, with none left empty.  They depend on the boxes only, not
+// on what has been kept: the tiles of chunk c+1 are computed by spare workgroups of the launch
+// that scans chunk c (the scan itself keeps one workgroup per image busy and leaves the rest of
+// the chip idle), into the other of two maskD buffers.
 constexpr int NMS_TRI = (NMS_CW / 2) * (NMS_CW + 1);
 static_assert(NMS_CW % 2 == 0, "the triangle folds in pairs of column blocks");
 
+// tile t of the chunk whose first column block is cb0; md = the image's maskD
+// [NMS_CW][NMS_COLS] (a word per column: bit r = row r of the row block suppresses it);
+// s_col: 64 entries of LDS private to the calling wave
+__device__ __forceinline__ void nms_tri_tile(const float4* __restrict__ bx, int K, int cb0, int t,
+                                             NBox* s_col, float thr, float c1, float thr_lo,
+                                             unsigned long long* __restrict__ md, int lane) {
+    const int p = t / (NMS_CW + 1), q = t - p * (NMS_CW + 1);
+    int jbl, ibl;
+    if (q <= p) { jbl = p; ibl = q; }
+    else { jbl = NMS_CW - 1 - p; ibl = q - p - 1; }
+    const int j = (cb0 + jbl) * 64 + lane;
+    if ((cb0 + jbl) * 64 >= K) return;                  // wave-uniform
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    s_col[lane] = norm_box(j < K ? bx[j] : zero4, thr_lo);
+    __builtin_amdgcn_wave_barrier();                    // one wave: its LDS operations stay in order
+    const int i = (cb0 + ibl) * 64 + lane;
+    const NBox a = norm_box(i < K ? bx[i] : zero4, thr_lo);
+    // a tiny row area could underflow the filter's products: +inf makes the filter pass
+    // whenever the boxes intersect, and the exact test decides
+    const float c1l = a.area < NMS_TINY_AREA ? __builtin_inff() : c1;
+    const unsigned long long mine = ibl == jbl ? mask_tile<true>(a, c1l, s_col, thr, lane)
+                                               : mask_tile<false>(a, c1l, s_col, thr, lane);
+    md[(size_t)ibl * NMS_COLS + jbl * 64 + lane] = mine;
+}
+
+// grid (NMS_CW * gk [+ NMS_TRI], 1, B), one wave per workgroup (one-wave workgroups also get
+// wave slots while another stream's kernel fills the chip).  NMS_CW * gk workgroups take the
+// KEPT row tiles: gk per column block, which share the block's tiles [0,nkt) with stride gk
+// (how many boxes are kept is only known on the device).  The first chunk's launch has no kept
+// tiles yet and NMS_TRI more workgroups for its own in-chunk tiles.  (One workgroup per
+// conceivable tile -- 48 per column block -- left most of them empty whenever few boxes are
+// kept, and an empty workgroup still holds a wave slot for the two dependent loads that tell
+// it so.)
+// Capped at 64 VGPRs: two such waves fit the registers one 128-VGPR wave of a kernel running
+// beside it frees.
+// maskK [B][NMS_CW][KT]: ONE word per (column block, kept tile), bit c = the tile suppresses
+// column c; maskD [B][NMS_CW][NMS_COLS].
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8)))
 nms_mask_kernel(const float4* __restrict__ boxes, int K, int cb0, int KT, int post_n, int gk,
                 float thr, float c1, float thr_lo, const int* __restrict__ done,
@@ -187,43 +220,30 @@ nms_mask_kernel(const float4* __restrict__ boxes, int K, int cb0, int KT, int po
     // the first chunk starts from an empty keep list and never reads count / done: the
     // workspace needs no clearing between calls
     if (cb0 != 0 && done[b]) return;
-    int jbl, part = 0, ibl = -1;                        // column block; kept role: part, else row block
-    {
-        const int n = (int)blockIdx.x;
-        if (n < NMS_CW * gk) {
-            jbl = n / gk;
-            part = n - jbl * gk;
-        } else {
-            const int t = n - NMS_CW * gk, p = t / (NMS_CW + 1), q = t - p * (NMS_CW + 1);
-            if (q <= p) { jbl = p; ibl = q; }
-            else { jbl = NMS_CW - 1 - p; ibl = q - p - 1; }
-        }
+    const int lane = lane_id();
+    __shared__ NBox s_col[64];
+    const float4* bx = boxes + (size_t)b * K;
+    const int n = (int)blockIdx.x;
+    if (n >= NMS_CW * gk) {
+        nms_tri_tile(bx, K, cb0, n - NMS_CW * gk, s_col, thr, c1, thr_lo,
+                     maskD + (size_t)b * NMS_CW * NMS_COLS, lane);
+        return;
     }
+    // Workgroup n runs on XCD n % 8: the column block is the fast index, so that the workgroups
+    // that find a kept tile when only a few boxes are kept (part 0) spread over every XCD; with
+    // part as the fast index they all met on one
+    const int part = n / NMS_CW, jbl = n - part * NMS_CW;
     const int jb = cb0 + jbl;
     if (jb * 64 >= K) return;
     const int count = cb0 != 0 ? count_g[b] : 0;        // boxes kept before this chunk
     const int nkt = (count + 63) >> 6;
-    if (ibl < 0 && part >= nkt) return;                 // no kept tile for this workgroup
-    const int lane = lane_id();
-    __shared__ NBox s_col[64];
-    const float4* bx = boxes + (size_t)b * K;
+    if (part >= nkt) return;                            // no kept tile for this workgroup
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     {
         const int j = jb * 64 + lane;
         s_col[lane] = norm_box(j < K ? bx[j] : zero4, thr_lo);
     }
-    __builtin_amdgcn_wave_barrier();                    // one wave: its LDS writes are in order
-    if (ibl >= 0) {
-        const int i = (cb0 + ibl) * 64 + lane;
-        const NBox a = norm_box(i < K ? bx[i] : zero4, thr_lo);
-        // a tiny row area could underflow the filter's products: +inf makes the filter pass
-        // whenever the boxes intersect, and the exact test decides
-        const float c1l = a.area < NMS_TINY_AREA ? __builtin_inff() : c1;
-        const unsigned long long mine = ibl == jbl ? mask_tile<true>(a, c1l, s_col, thr, lane)
-                                                   : mask_tile<false>(a, c1l, s_col, thr, lane);
-        maskD[((size_t)b * NMS_CW + ibl) * NMS_COLS + jbl * 64 + lane] = mine;
-        return;
-    }
+    __builtin_amdgcn_wave_barrier();                    // one wave: its LDS operations stay in order
 #pragma unroll 1
     for (int rt = part; rt < nkt; rt += gk) {
         const int slot = rt * 64 + lane;
@@ -234,19 +254,39 @@ nms_mask_kernel(const float4* __restrict__ boxes, int K, int cb0, int KT, int po
     }
 }
 
-// One workgroup (NMS_SCAN_WAVES waves) per image walks the chunk's column blocks in order.
+// Workgroups 0 .. nimg-1 (NMS_SCAN_WAVES waves each): one per image walks the chunk's column
+// blocks in order.  With maskD_next, nimg * NMS_TRI_WGS more: wave = one in-chunk tile of the
+// NEXT chunk (nms_tri_tile), which needs nothing from this scan.
+constexpr int NMS_TRI_WGS = (NMS_TRI + NMS_SCAN_WAVES - 1) / NMS_SCAN_WAVES;
+
 __global__ void __launch_bounds__(64 * NMS_SCAN_WAVES)
 nms_scan_kernel(const float4* __restrict__ boxes, const unsigned long long* __restrict__ maskK,
-                const unsigned long long* __restrict__ maskD, int K, int cb0, int KT, int post_n,
-                int last_chunk, int* __restrict__ count_g, int* __restrict__ done,
+                const unsigned long long* __restrict__ maskD,
+                unsigned long long* __restrict__ maskD_next, int nimg, int K, int cb0, int KT,
+                int post_n, int last_chunk, float thr, float c1, float thr_lo,
+                int* __restrict__ count_g, int* __restrict__ done,
                 int32_t* __restrict__ keep_idx, float4* __restrict__ proposed,
                 int32_t* __restrict__ keep_pos, int32_t* __restrict__ keep_count) {
     __shared__ unsigned long long keptw[NMS_CW];        // keep bits of this chunk's blocks
     __shared__ unsigned long long deadw[NMS_SCAN_WAVES];
     __shared__ int s_cnt;
+    __shared__ NBox s_tri[NMS_SCAN_WAVES][64];
+    const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
+    if ((int)blockIdx.x >= nimg) {
+        const int n = (int)blockIdx.x - nimg, bt = n / NMS_TRI_WGS;
+        const int t = (n - bt * NMS_TRI_WGS) * NMS_SCAN_WAVES + wave;
+        // an image finished by an earlier chunk has no next chunk (the first chunk's launch
+        // finds `done` as the previous call left it and does not look; an image that this
+        // very launch finishes may or may not be seen as done: its tiles are never read)
+        if (t >= NMS_TRI || (cb0 != 0 && done[bt])) return;
+        nms_tri_tile(boxes + (size_t)bt * K, K, cb0 + NMS_CW, t, s_tri[wave], thr, c1, thr_lo,
+                     maskD_next + (size_t)bt * NMS_CW * NMS_COLS, lane);
+        return;
+    }
     const int b = blockIdx.x;
     if (cb0 != 0 && done[b]) return;                    // block-uniform
-    const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
+    // the walk is one dependent chain: its waves go first where they share a CU with tile waves
+    __builtin_amdgcn_s_setprio(3);
     const float4* bx = boxes + (size_t)b * K;
     const unsigned long long* mk = maskK + (size_t)b * NMS_CW * KT;
     const unsigned long long* md = maskD + (size_t)b * NMS_CW * NMS_COLS;
@@ -405,17 +445,17 @@ extern "C" int frcnn_topk(const float* scores, int B, int N, int K, const float*
     return FRCNN_OK;
 }
 
-// workspace = maskK [B][KT][NMS_COLS] u64 | maskD [B][NMS_CW][NMS_COLS] u64 |
+// workspace = maskK [B][NMS_CW][KT] u64 | maskD [2][B][NMS_CW][NMS_COLS] u64 |
 //             keep_idx [B][post_n] i32 | count [B] i32 | done [B] i32
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 static size_t nms_maskk_bytes(int B, int post_n) {
-    return align256((size_t)B * ((size_t)(post_n + 63) / 64) * NMS_COLS * 8);
+    return align256((size_t)B * NMS_CW * ((size_t)(post_n + 63) / 64) * 8);
 }
 static size_t nms_maskd_bytes(int B) { return align256((size_t)B * NMS_CW * NMS_COLS * 8); }
 
 extern "C" size_t frcnn_nms_workspace_bytes(int B, int K, int post_n) {
     if (B <= 0 || K <= 0 || post_n <= 0) return 0;
-    return nms_maskk_bytes(B, post_n) + nms_maskd_bytes(B) + align256((size_t)B * post_n * 4) +
+    return nms_maskk_bytes(B, post_n) + 2 * nms_maskd_bytes(B) + align256((size_t)B * post_n * 4) +
            align256((size_t)B * 8);
 }
 
@@ -428,7 +468,10 @@ static int nms_launch(const float* boxes, int B, int K, float iou_threshold, int
     if (B > 65535) return FRCNN_E_UNSUPPORTED;
     unsigned long long* maskK = reinterpret_cast<unsigned long long*>(ws);
     ws += nms_maskk_bytes(B, post_n);
-    unsigned long long* maskD = reinterpret_cast<unsigned long long*>(ws);
+    unsigned long long* maskD[2];
+    maskD[0] = reinterpret_cast<unsigned long long*>(ws);
+    ws += nms_maskd_bytes(B);
+    maskD[1] = reinterpret_cast<unsigned long long*>(ws);
     ws += nms_maskd_bytes(B);
     int32_t* keep_idx = reinterpret_cast<int32_t*>(ws);
     ws += align256((size_t)B * post_n * 4);
@@ -442,15 +485,19 @@ static int nms_launch(const float* boxes, int B, int K, float iou_threshold, int
     int gk = (16384 + NMS_CW * B - 1) / (NMS_CW * B);
     if (const char* e = getenv("FRCNN_NMS_GK")) gk = atoi(e);
     gk = gk < 1 ? 1 : gk > KT ? KT : gk;
-    for (int cb0 = 0; cb0 < CB; cb0 += NMS_CW) {
+    if ((long long)B * (1 + NMS_TRI_WGS) > 0x7FFFFFFFll) return FRCNN_E_UNSUPPORTED;
+    for (int cb0 = 0, ci = 0; cb0 < CB; cb0 += NMS_CW, ++ci) {
         const int last = cb0 + NMS_CW >= CB;
-        FRCNN_LAUNCH(nms_mask_kernel, dim3(NMS_CW * gk + NMS_TRI, 1, B), dim3(64), 0, st,
-                     reinterpret_cast<const float4*>(boxes), K, cb0, KT, post_n, gk, iou_threshold,
-                     c1, thr_lo, done, count, keep_idx, maskK, maskD);
-        FRCNN_LAUNCH(nms_scan_kernel, dim3(B), dim3(64 * NMS_SCAN_WAVES), 0, st,
-                     reinterpret_cast<const float4*>(boxes), maskK, maskD, K, cb0, KT, post_n, last,
-                     count, done, keep_idx, reinterpret_cast<float4*>(proposed), keep_pos,
-                     keep_count);
+        // chunk ci's in-chunk tiles are in maskD[ci & 1]: written by this launch for the first
+        // chunk, by the spare workgroups of the previous chunk's scan for the others
+        FRCNN_LAUNCH(nms_mask_kernel, dim3(NMS_CW * gk + (ci == 0 ? NMS_TRI : 0), 1, B), dim3(64), 0,
+                     st, reinterpret_cast<const float4*>(boxes), K, cb0, KT, post_n, gk,
+                     iou_threshold, c1, thr_lo, done, count, keep_idx, maskK, maskD[ci & 1]);
+        FRCNN_LAUNCH(nms_scan_kernel, dim3(last ? B : B * (1 + NMS_TRI_WGS)),
+                     dim3(64 * NMS_SCAN_WAVES), 0, st, reinterpret_cast<const float4*>(boxes), maskK,
+                     maskD[ci & 1], last ? nullptr : maskD[(ci + 1) & 1], B, K, cb0, KT, post_n, last,
+                     iou_threshold, c1, thr_lo, count, done, keep_idx,
+                     reinterpret_cast<float4*>(proposed), keep_pos, keep_count);
     }
     return FRCNN_OK;
 }
