@@ -209,13 +209,14 @@ __device__ __forceinline__ void nms_tri_tile(const float4* __restrict__ bx, int 
 // it so.)
 // Capped at 64 VGPRs: two such waves fit the registers one 128-VGPR wave of a kernel running
 // beside it frees.
-// maskK [B][NMS_CW][KT]: ONE word per (column block, kept tile), bit c = the tile suppresses
-// column c; maskD [B][NMS_CW][NMS_COLS].
+// deadK [B][NMS_CW]: ONE word per column block, bit c = some kept box suppresses column c:
+// every kept tile ORs its word in (the scan hands the words back as zeros);
+// maskD [B][NMS_CW][NMS_COLS].
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8)))
-nms_mask_kernel(const float4* __restrict__ boxes, int K, int cb0, int KT, int post_n, int gk,
+nms_mask_kernel(const float4* __restrict__ boxes, int K, int cb0, int post_n, int gk,
                 float thr, float c1, float thr_lo, const int* __restrict__ done,
                 const int* __restrict__ count_g, const int32_t* __restrict__ keep_idx,
-                unsigned long long* __restrict__ maskK, unsigned long long* __restrict__ maskD) {
+                unsigned long long* __restrict__ deadK, unsigned long long* __restrict__ maskD) {
     const int b = blockIdx.z;
     // the first chunk starts from an empty keep list and never reads count / done: the
     // workspace needs no clearing between calls
@@ -250,7 +251,7 @@ nms_mask_kernel(const float4* __restrict__ boxes, int K, int cb0, int KT, int po
         const NBox a = norm_box(slot < count ? bx[keep_idx[(size_t)b * post_n + slot]] : zero4, thr_lo);
         const float c1l = a.area < NMS_TINY_AREA ? __builtin_inff() : c1;
         const unsigned long long dead = mask_tile_any(a, c1l, s_col, thr);
-        if (lane == 0) maskK[((size_t)b * NMS_CW + jbl) * KT + rt] = dead;
+        if (lane == 0 && dead != 0ull) atomicOr(&deadK[(size_t)b * NMS_CW + jbl], dead);
     }
 }
 
@@ -260,15 +261,16 @@ nms_mask_kernel(const float4* __restrict__ boxes, int K, int cb0, int KT, int po
 constexpr int NMS_TRI_WGS = (NMS_TRI + NMS_SCAN_WAVES - 1) / NMS_SCAN_WAVES;
 
 __global__ void __launch_bounds__(64 * NMS_SCAN_WAVES)
-nms_scan_kernel(const float4* __restrict__ boxes, const unsigned long long* __restrict__ maskK,
+nms_scan_kernel(const float4* __restrict__ boxes, unsigned long long* __restrict__ deadK,
                 const unsigned long long* __restrict__ maskD,
-                unsigned long long* __restrict__ maskD_next, int nimg, int K, int cb0, int KT,
+                unsigned long long* __restrict__ maskD_next, int nimg, int K, int cb0,
                 int post_n, int last_chunk, float thr, float c1, float thr_lo,
                 int* __restrict__ count_g, int* __restrict__ done,
                 int32_t* __restrict__ keep_idx, float4* __restrict__ proposed,
                 int32_t* __restrict__ keep_pos, int32_t* __restrict__ keep_count) {
     __shared__ unsigned long long keptw[NMS_CW];        // keep bits of this chunk's blocks
     __shared__ unsigned long long deadw[NMS_SCAN_WAVES];
+    __shared__ unsigned long long deadk_s[NMS_CW];      // columns the kept boxes suppress, per block
     __shared__ int s_cnt;
     __shared__ NBox s_tri[NMS_SCAN_WAVES][64];
     const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
@@ -288,46 +290,41 @@ nms_scan_kernel(const float4* __restrict__ boxes, const unsigned long long* __re
     // the walk is one dependent chain: its waves go first where they share a CU with tile waves
     __builtin_amdgcn_s_setprio(3);
     const float4* bx = boxes + (size_t)b * K;
-    const unsigned long long* mk = maskK + (size_t)b * NMS_CW * KT;
     const unsigned long long* md = maskD + (size_t)b * NMS_CW * NMS_COLS;
     float4* prop = proposed + (size_t)b * post_n;
     int32_t* kidx = keep_idx + (size_t)b * post_n;
     int32_t* kp = keep_pos ? keep_pos + (size_t)b * post_n : nullptr;
     const int count0 = cb0 != 0 ? count_g[b] : 0;
-    const int nkt = (count0 + 63) >> 6;
     if (tid == 0) s_cnt = count0;
+    // the kept tiles' words of this chunk, handed back as zeros for the next chunk's tiles (the
+    // first chunk has no kept tiles: whatever an earlier call left there is dropped)
+    if (tid < NMS_CW) {
+        unsigned long long* dk = deadK + (size_t)b * NMS_CW + tid;
+        const unsigned long long v = *dk;
+        *dk = 0ull;
+        deadk_s[tid] = cb0 != 0 ? v : 0ull;
+    }
     __syncthreads();
     const int nblk = min(NMS_CW, (K + 63) / 64 - cb0);
     // Everything a column block needs from memory is independent of the scan's own results
-    // (the kept-tile words, the raw in-chunk words, the diagonal word, the box), so block
-    // the loads of a later block are issued before block jbl is resolved and the serial part
-    // sees no load latency.  A wave owns kept tiles wave, wave+SW, ... and
-    // in-chunk rows wave, wave+SW, ...
+    // (the raw in-chunk words, the diagonal word, the box), so the loads of a later block are
+    // issued before block jbl is resolved and the serial part sees no load latency.  A wave
+    // owns the in-chunk rows wave, wave+SW, ...; rows at or beyond the block itself have
+    // no tile: their words are read (whatever they hold) and dropped, which keeps branches out
+    // of the walk.
     constexpr int SW = NMS_SCAN_WAVES;
-    // a wave holds at most KMAX kept-tile words (wave-uniform: one word per tile and column
-    // block) raw until the block is resolved (an OR here would wait for the loads inside the
-    // prefetch); the rest (post_n > 64 * SW * KMAX) are folded in at once
-    constexpr int KMAX = 8;
-    struct Pre { unsigned long long hk[KMAX], more, diag, mdw[NMS_CW / SW]; float4 box; };
+    struct Pre { unsigned long long diag, mdw[NMS_CW / SW]; float4 box; };
     auto prefetch = [&](int jbl) {
         Pre p;
         const int col = jbl * 64 + lane;
-        p.diag = wave == 0 ? md[(size_t)jbl * NMS_COLS + col] : 0ull;
-        const unsigned long long* mkb = mk + (size_t)jbl * KT;
-#pragma unroll
-        for (int t = 0; t < KMAX; ++t) {
-            const int kt = wave + SW * t;
-            p.hk[t] = kt < nkt ? mkb[kt] : 0ull;
-        }
-        p.more = 0ull;
-        for (int kt = wave + SW * KMAX; kt < nkt; kt += SW) p.more |= mkb[kt];
+        p.diag = md[(size_t)jbl * NMS_COLS + col];
 #pragma unroll
         for (int t = 0; t < NMS_CW / SW; ++t) {
             const int ibl = wave + SW * t;
-            p.mdw[t] = ibl < jbl ? md[(size_t)ibl * NMS_COLS + col] : 0ull;
+            p.mdw[t] = md[(size_t)ibl * NMS_COLS + col];
         }
         const int j = (cb0 + jbl) * 64 + lane;
-        p.box = (wave == 0 && j < K) ? bx[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        p.box = bx[j < K ? j : K - 1];
         return p;
     };
     Pre cur = prefetch(0);
@@ -347,9 +344,6 @@ nms_scan_kernel(const float4* __restrict__ boxes, const unsigned long long* __re
         if (jbl + 1 < nblk) nxt = prefetch(jbl + 1);    // block-uniform, one block ahead
 #endif
         const int j0 = (cb0 + jbl) * 64;
-        unsigned long long by_kept = cur.more;          // columns a kept tile of this wave suppresses
-#pragma unroll
-        for (int t = 0; t < KMAX; ++t) by_kept |= cur.hk[t];
         unsigned long long hit = 0ull;
 #pragma unroll
         for (int t = 0; t < NMS_CW / SW; ++t) {
@@ -357,7 +351,7 @@ nms_scan_kernel(const float4* __restrict__ boxes, const unsigned long long* __re
             if (ibl < jbl) hit |= cur.mdw[t] & keptw[ibl];
         }
         const unsigned long long diag = cur.diag;
-        const unsigned long long dead = uniform64(by_kept) | __ballot(hit != 0ull);
+        const unsigned long long dead = __ballot(hit != 0ull);
         if (lane == 0) deadw[wave] = dead;
         __syncthreads();
         if (wave == 0) {
@@ -368,7 +362,7 @@ nms_scan_kernel(const float4* __restrict__ boxes, const unsigned long long* __re
             // A column whose suppressors are all dead is kept; one with a kept suppressor is
             // dead; the lowest undecided column is always decidable, so the loop ends, and its
             // fixed point is the greedy result.  Typical depth: a handful of rounds.
-            unsigned long long any_dead = 0ull;
+            unsigned long long any_dead = deadk_s[jbl];
 #pragma unroll
             for (int w = 0; w < SW; ++w) any_dead |= deadw[w];
             unsigned long long gone = uniform64(any_dead | ~vmask);
@@ -445,17 +439,15 @@ extern "C" int frcnn_topk(const float* scores, int B, int N, int K, const float*
     return FRCNN_OK;
 }
 
-// workspace = maskK [B][NMS_CW][KT] u64 | maskD [2][B][NMS_CW][NMS_COLS] u64 |
+// workspace = deadK [B][NMS_CW] u64 | maskD [2][B][NMS_CW][NMS_COLS] u64 |
 //             keep_idx [B][post_n] i32 | count [B] i32 | done [B] i32
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
-static size_t nms_maskk_bytes(int B, int post_n) {
-    return align256((size_t)B * NMS_CW * ((size_t)(post_n + 63) / 64) * 8);
-}
+static size_t nms_deadk_bytes(int B) { return align256((size_t)B * NMS_CW * 8); }
 static size_t nms_maskd_bytes(int B) { return align256((size_t)B * NMS_CW * NMS_COLS * 8); }
 
 extern "C" size_t frcnn_nms_workspace_bytes(int B, int K, int post_n) {
     if (B <= 0 || K <= 0 || post_n <= 0) return 0;
-    return nms_maskk_bytes(B, post_n) + 2 * nms_maskd_bytes(B) + align256((size_t)B * post_n * 4) +
+    return nms_deadk_bytes(B) + 2 * nms_maskd_bytes(B) + align256((size_t)B * post_n * 4) +
            align256((size_t)B * 8);
 }
 
@@ -466,8 +458,8 @@ static int nms_launch(const float* boxes, int B, int K, float iou_threshold, int
     const int CB = (K + 63) / 64;
     const int KT = (post_n + 63) / 64;
     if (B > 65535) return FRCNN_E_UNSUPPORTED;
-    unsigned long long* maskK = reinterpret_cast<unsigned long long*>(ws);
-    ws += nms_maskk_bytes(B, post_n);
+    unsigned long long* deadK = reinterpret_cast<unsigned long long*>(ws);
+    ws += nms_deadk_bytes(B);
     unsigned long long* maskD[2];
     maskD[0] = reinterpret_cast<unsigned long long*>(ws);
     ws += nms_maskd_bytes(B);
@@ -491,11 +483,11 @@ static int nms_launch(const float* boxes, int B, int K, float iou_threshold, int
         // chunk ci's in-chunk tiles are in maskD[ci & 1]: written by this launch for the first
         // chunk, by the spare workgroups of the previous chunk's scan for the others
         FRCNN_LAUNCH(nms_mask_kernel, dim3(NMS_CW * gk + (ci == 0 ? NMS_TRI : 0), 1, B), dim3(64), 0,
-                     st, reinterpret_cast<const float4*>(boxes), K, cb0, KT, post_n, gk,
-                     iou_threshold, c1, thr_lo, done, count, keep_idx, maskK, maskD[ci & 1]);
+                     st, reinterpret_cast<const float4*>(boxes), K, cb0, post_n, gk,
+                     iou_threshold, c1, thr_lo, done, count, keep_idx, deadK, maskD[ci & 1]);
         FRCNN_LAUNCH(nms_scan_kernel, dim3(last ? B : B * (1 + NMS_TRI_WGS)),
-                     dim3(64 * NMS_SCAN_WAVES), 0, st, reinterpret_cast<const float4*>(boxes), maskK,
-                     maskD[ci & 1], last ? nullptr : maskD[(ci + 1) & 1], B, K, cb0, KT, post_n, last,
+                     dim3(64 * NMS_SCAN_WAVES), 0, st, reinterpret_cast<const float4*>(boxes), deadK,
+                     maskD[ci & 1], last ? nullptr : maskD[(ci + 1) & 1], B, K, cb0, post_n, last,
                      iou_threshold, c1, thr_lo, count, done, keep_idx,
                      reinterpret_cast<float4*>(proposed), keep_pos, keep_count);
     }

@@ -37,9 +37,9 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     L = _lib.lib
     kt = (1500 + 63) // 64
     up = lambda v: (v + 255) // 256 * 256
-    # one word per (column block, kept tile), two buffers of a word per in-chunk column and
-    # row block, the kept index list, count and done
-    assert L.frcnn_nms_workspace_bytes(2, 6000, 1500) == (up(2 * 16 * kt * 8) + 2 * 2 * 16 * 1024 * 8
+    # one word per column block, two buffers of a word per in-chunk column and row block, the
+    # kept index list, count and done
+    assert L.frcnn_nms_workspace_bytes(2, 6000, 1500) == (up(2 * 16 * 8) + 2 * 2 * 16 * 1024 * 8
                                                           + up(2 * 1500 * 4) + up(2 * 8))
     assert L.frcnn_nms_workspace_bytes(2, 100000, 1500) == L.frcnn_nms_workspace_bytes(2, 6000, 1500)
     assert L.frcnn_nms_workspace_bytes(0, 10, 5) == 0
