@@ -56,9 +56,8 @@ class RegionProposalPath:
         self.train, self.fuse_pool, self.depth = train, fuse_pool, depth
         self.side = torch.cuda.Stream(self.device) if train else None
         self.prop_stream = torch.cuda.Stream(self.device) if depth == 2 else None
-        # the RoI geometry (frcnn_roi_fwd_prepare) is computed beside both chains: behind the NMS,
-        # but neither in front of the next batch's top-k nor in front of the RoI kernel
-        self.prep_stream = torch.cuda.Stream(self.device) if depth == 2 else None
+        # the RoI geometry (frcnn_roi_fwd_prepare) is computed on the proposal stream right behind
+        # the NMS, not in front of the RoI kernel (a stream of its own for it measured the same)
         self._calls = 0
         dev, B, N = self.device, batch, cfg.N
         f32, i32, i64, u8 = torch.float32, torch.int32, torch.int64, torch.uint8
@@ -184,10 +183,31 @@ class RegionProposalPath:
             ready.record(main)
         if self.depth == 2:
             prop.wait_event(ready)
-            if self._calls > self.depth:
-                prop.wait_event(ev[4])
         elif inputs_ready is not None:
             main.wait_event(ready)                     # inputs may come from another stream
+        if self.topk == "sort":
+            check("frcnn_topk_sort", lib.frcnn_topk_sort(
+                _p(score), B, N, cfg.pre_k, _p(self.anchor), _p(coord), _p(d["top_scores"]),
+                _p(d["top_idx"]), _p(d["cand"]), _p(d["topk_ws"]), d["topk_ws"].numel(), ps))
+        else:
+            check("frcnn_topk", lib.frcnn_topk(
+                _p(score), B, N, cfg.pre_k, _p(self.anchor), _p(coord), _p(d["top_scores"]),
+                _p(d["top_idx"]), _p(d["cand"]), ps))
+        # The top-k writes buffers that only this stream reads, so it may run while the set's
+        # previous user (two calls ago) is still busy; the NMS rewrites `proposed`, which that
+        # user's RoI and target kernels read until the point ev[4] marks.  (With small images
+        # the proposal chain is the longer one: it has to start as early as it can.)
+        if self.depth == 2 and self._calls > self.depth:
+            prop.wait_event(ev[4])
+        if nms_events is not None:
+            nms_events[0].record(prop)
+        check("frcnn_nms", lib.frcnn_nms(
+            _p(d["cand"]), B, cfg.pre_k, cfg.nms_thr, cfg.post_n, _p(d["proposed"]),
+            _p(d["keep_pos"]), _p(d["keep_count"]), _p(d["nms_ws"]), d["nms_ws"].numel(), ps))
+        if nms_events is not None:
+            nms_events[1].record(prop)
+        ev[1].record(prop)                             # proposals ready
+        # (the host queues the proposal chain first: with small images it is the longer one)
         if self.train:
             G = gt.shape[1]
             ss = self.side.cuda_stream
@@ -203,27 +223,9 @@ class RegionProposalPath:
                 _p(d["flags"]), None, None, None, seed, image_base, cfg.rpn_batch, cfg.rpn_max_pos,
                 _p(r["label"]), _p(r["anchor"]), _p(r["gt"]), _p(r["gt_list"]), _p(r["pos"]),
                 _p(r["reg"]), _p(r["counts"]), ss))
-        if self.topk == "sort":
-            check("frcnn_topk_sort", lib.frcnn_topk_sort(
-                _p(score), B, N, cfg.pre_k, _p(self.anchor), _p(coord), _p(d["top_scores"]),
-                _p(d["top_idx"]), _p(d["cand"]), _p(d["topk_ws"]), d["topk_ws"].numel(), ps))
-        else:
-            check("frcnn_topk", lib.frcnn_topk(
-                _p(score), B, N, cfg.pre_k, _p(self.anchor), _p(coord), _p(d["top_scores"]),
-                _p(d["top_idx"]), _p(d["cand"]), ps))
-        if nms_events is not None:
-            nms_events[0].record(prop)
-        check("frcnn_nms", lib.frcnn_nms(
-            _p(d["cand"]), B, cfg.pre_k, cfg.nms_thr, cfg.post_n, _p(d["proposed"]),
-            _p(d["keep_pos"]), _p(d["keep_count"]), _p(d["nms_ws"]), d["nms_ws"].numel(), ps))
-        if nms_events is not None:
-            nms_events[1].record(prop)
-        ev[1].record(prop)                             # proposals ready
         prepared = 0
         if not skip_roi:
-            prep = self.prep_stream if self.depth == 2 else main
-            if self.depth == 2:
-                prep.wait_event(ev[1])
+            prep = prop
             prepared = lib.frcnn_roi_fwd_prepare(
                 _p(d["proposed"]), B, cfg.H, cfg.W, self.C, cfg.post_n, cfg.crop[0], cfg.crop[1],
                 self.pool, int(self.winner is not None), _p(d["roi_ws"]), d["roi_ws"].numel(),
