@@ -130,6 +130,24 @@ def test_fuzz_nms(seed, B, K, post_n, thr, mode):
     np.testing.assert_array_equal(prop.cpu().numpy(), rp)
 
 
+@pytest.mark.parametrize("gk", [1, 2, 3, 5])
+@pytest.mark.parametrize("mode", ["uniform", "clustered", "degenerate"])
+def test_nms_kept_tiles_shared_with_a_stride(gk, mode, monkeypatch):
+    """With many images a mask workgroup takes several kept tiles of a column block in turn
+    (stride gk); forced here on a small batch, with enough kept boxes for several tiles and
+    candidates beyond the second chunk."""
+    from objectdetection_amd import ops
+    monkeypatch.setenv("FRCNN_NMS_GK", str(gk))
+    rng = np.random.default_rng(100 + gk)
+    B, K, post_n, thr = 3, 2600, 700, 0.7
+    boxes = np.stack([np.clip(draw_boxes(rng, K, mode), 0, 1) for _ in range(B)])
+    prop, keep, cnt = ops.nms(T(boxes), thr, post_n)
+    rp, rk, rc = O.combined_nms(boxes, None, post_n, thr)
+    np.testing.assert_array_equal(cnt.cpu().numpy(), rc)
+    np.testing.assert_array_equal(keep.cpu().numpy(), rk)
+    np.testing.assert_array_equal(prop.cpu().numpy(), rp)
+
+
 CROPS = st.sampled_from([((14, 14), 2), ((14, 14), 1), ((7, 7), 1), ((6, 10), 2), ((2, 2), 2),
                          ((1, 1), 1), ((4, 4), 2), ((16, 16), 2), ((3, 5), 1)])
 
