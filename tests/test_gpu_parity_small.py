@@ -241,6 +241,28 @@ def test_roi_backward_exact_shapes(dev, C, pool, crop, R):
     np.testing.assert_array_equal(got.cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("chunk,cx", [("64", "2"), ("128", "1"), ("64", "1")])
+def test_roi_backward_in_ranges_of_rois(dev, chunk, cx, monkeypatch):
+    """From 32 images the backward is launched per range of RoIs (later ranges continue the
+    earlier sums), and a wave may own one cell instead of two: both forced here on a small
+    batch; the sums must not depend on either."""
+    from objectdetection_amd import ops
+    monkeypatch.setenv("FRCNN_BWD_CHUNK", chunk)
+    monkeypatch.setenv("FRCNN_BWD_CX", cx)
+    rng = np.random.default_rng(int(chunk) + int(cx))
+    B, H, W, C, R = 2, 11, 15, 192, 150
+    fm = np.maximum(rng.standard_normal((B, H, W, C)).astype(np.float32), 0)
+    y1 = rng.uniform(-0.05, 0.7, (B, R)); x1 = rng.uniform(-0.05, 0.7, (B, R))
+    prop = np.stack([y1, x1, y1 + rng.uniform(0.02, 0.6, (B, R)), x1 + rng.uniform(0.02, 0.6, (B, R))],
+                    -1).astype(np.float32)
+    out, win = ops.roi_crop_pool_fwd(T(fm, dev), T(prop, dev), (14, 14), 2, want_winner=True)
+    ro, ra = O.roi_crop_pool(fm, prop, (14, 14), 2)
+    dY = rng.standard_normal(ro.shape).astype(np.float32)
+    got = ops.roi_crop_pool_bwd(T(dY, dev), win, T(prop, dev), fm.shape, (14, 14), 2)
+    ref = O.roi_crop_pool_bwd(dY, ra, fm.shape, prop, (14, 14), 2)
+    np.testing.assert_array_equal(got.cpu().numpy(), ref)
+
+
 @pytest.mark.parametrize("mode", ["keys", "philox"])
 def test_making_frcnn_input(dev, ref_inputs, mode):
     from objectdetection_amd import ops
