@@ -8,11 +8,13 @@
 //
 // Four passes over 8-bit digits of the ascending key desc_key(score); per pass
 //   hist    : per 1024-element block, digit histogram                         [B][nblk][256]
-//   offsets : per image, exclusive scan over (digit, block) -> first output place of every
-//             (block, digit)
-//   scatter : every element goes to offsets[block][digit] + its rank among the block's
-//             elements of that digit (rank in element order = stable)
-// and a final gather of the first K.  gfx950, wave64.
+//   scatter : every block first derives the output place of its first element of every digit
+//             from the image's histograms (exclusive scan over (digit, block): a few hundred
+//             instructions per block, cheaper than a launch of its own between the two
+//             kernels while another stream's kernel fills the chip), then every element
+//             goes to that place + its rank among the block's elements of that digit (rank in
+//             element order = stable)
+// and a final gather of the first K: nine launches.  gfx950, wave64.
 #include "frcnn_common.h"
 
 namespace frcnn {
@@ -84,49 +86,43 @@ ts_hist_kernel(const float* __restrict__ scores, const uint32_t* __restrict__ ke
             *(volatile uint32_t*)&h[t * 64 + lane];
 }
 
-// one wave per image, lane = four consecutive digits: hist[b][blk][d] becomes the output place
-// of the first element of (blk, d)
-__global__ void __launch_bounds__(64)
-ts_offsets_kernel(int nblk, uint32_t* __restrict__ hist) {
-    const int b = blockIdx.x, lane = threadIdx.x;
-    uint4* h = reinterpret_cast<uint4*>(hist + (size_t)b * nblk * 256) + lane;   // digits 4l..4l+3
-    uint4 total = make_uint4(0, 0, 0, 0);
-    for (int blk = 0; blk < nblk; ++blk) {
-        const uint4 v = h[(size_t)blk * 64];
-        total.x += v.x; total.y += v.y; total.z += v.z; total.w += v.w;
-    }
-    const uint32_t mine = total.x + total.y + total.z + total.w;
-    uint32_t incl = mine;
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) {
-        const uint32_t o = __shfl_up(incl, s);
-        if (lane >= s) incl += o;
-    }
-    uint4 run;
-    run.x = incl - mine;
-    run.y = run.x + total.x;
-    run.z = run.y + total.y;
-    run.w = run.z + total.z;
-    for (int blk = 0; blk < nblk; ++blk) {
-        const uint4 v = h[(size_t)blk * 64];
-        h[(size_t)blk * 64] = run;
-        run.x += v.x; run.y += v.y; run.z += v.z; run.w += v.w;
-    }
-}
-
 template <int PASS>
 __global__ void __launch_bounds__(64)
 ts_scatter_kernel(const float* __restrict__ scores, const uint32_t* __restrict__ keys_in,
                   const int32_t* __restrict__ idx_in, int N, int nblk, int B,
-                  const uint32_t* __restrict__ offsets, uint32_t* __restrict__ keys_out,
+                  const uint32_t* __restrict__ hist, uint32_t* __restrict__ keys_out,
                   int32_t* __restrict__ idx_out) {
-    __shared__ uint32_t nextpos[256];                // next output place of each digit
+    __shared__ __attribute__((aligned(16))) uint32_t nextpos[256];   // next output place of each digit
     const int lane = threadIdx.x;
     int blk, b;
     ts_block_of((int)blockIdx.x, nblk, B, blk, b);
-    const uint32_t* off = offsets + ((size_t)b * nblk + blk) * 256;
+    {
+        // lane = four consecutive digits.  Elements of digit d in blocks before this one, and
+        // in all blocks; the first place of (this block, d) = elements of smaller digits
+        // anywhere + elements of d in earlier blocks.
+        const uint4* h = reinterpret_cast<const uint4*>(hist + (size_t)b * nblk * 256) + lane;
+        uint4 total = make_uint4(0, 0, 0, 0), before = make_uint4(0, 0, 0, 0);
+#pragma unroll 4
+        for (int k = 0; k < nblk; ++k) {
+            const uint4 v = h[(size_t)k * 64];
+            total.x += v.x; total.y += v.y; total.z += v.z; total.w += v.w;
+            if (k < blk) { before.x += v.x; before.y += v.y; before.z += v.z; before.w += v.w; }
+        }
+        const uint32_t mine = total.x + total.y + total.z + total.w;
+        uint32_t incl = mine;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) nextpos[t * 64 + lane] = off[t * 64 + lane];
+        for (int s = 1; s < 64; s <<= 1) {
+            const uint32_t o = __shfl_up(incl, s);
+            if (lane >= s) incl += o;
+        }
+        uint4 first;
+        first.x = incl - mine;
+        first.y = first.x + total.x;
+        first.z = first.y + total.y;
+        first.w = first.z + total.z;
+        first.x += before.x; first.y += before.y; first.z += before.z; first.w += before.w;
+        *reinterpret_cast<uint4*>(&nextpos[4 * lane]) = first;
+    }
     __builtin_amdgcn_wave_barrier();
     const size_t base = (size_t)b * N;
     // the wave takes its 1024 elements 64 at a time, so (item, lane) order is element order
@@ -210,7 +206,6 @@ extern "C" int frcnn_topk_sort(const float* scores, int B, int N, int K, const f
     const dim3 grid((unsigned)((long long)nblk * B)), block(64);
 #define TS_PASS(P, KIN, IIN, KOUT, IOUT)                                                          \
     FRCNN_LAUNCH(ts_hist_kernel<P>, grid, block, 0, st, scores, KIN, N, nblk, B, hist);           \
-    FRCNN_LAUNCH(ts_offsets_kernel, dim3(B), dim3(64), 0, st, nblk, hist);                       \
     FRCNN_LAUNCH(ts_scatter_kernel<P>, grid, block, 0, st, scores, KIN, IIN, N, nblk, B, hist, KOUT, \
                  IOUT)
     TS_PASS(0, (const uint32_t*)nullptr, (const int32_t*)nullptr, keys[0], idx[0]);

@@ -235,9 +235,9 @@ class RegionProposalPath:
             if self.depth == 2:
                 ev[3].record(prep)
         if self.depth == 2:
-            main.wait_event(ev[1])
-            if not skip_roi:
-                main.wait_event(ev[3])
+            # one wait on `main` (every event packet between two RoI kernels is time in which
+            # the stream does nothing): the geometry is written behind the NMS on the same stream
+            main.wait_event(ev[1] if skip_roi else ev[3])
         if self.train:
             self.side.wait_event(ev[1])
             ss = self.side.cuda_stream
