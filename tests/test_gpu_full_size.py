@@ -198,9 +198,10 @@ def test_config4_batch64_two_batches_in_flight(dev):
             ro, _ = c_oracle.roi_crop_pool(lib, f[b].cpu().numpy(), prop[b], cfg.crop, cfg.pool,
                                            want_winner=False)
             np.testing.assert_array_equal(got[i]["pooled"][j].cpu().numpy(), ro)
-        # keep list of two images against the sequential greedy NMS on the device's candidates
+        # keep lists against the sequential greedy NMS on the device's candidates: every image
+        # of the first batch, two of the others
         cand = plain.cand.cpu().numpy()
-        for b in (5, 60):
+        for b in (range(B) if i == 0 else (5, 60)):
             rp, rk, rc = c_oracle.nms(lib, cand[b], cfg.nms_thr, cfg.post_n)
             np.testing.assert_array_equal(got[i]["keep_pos"][b].cpu().numpy(), rk)
             np.testing.assert_array_equal(got[i]["proposed"][b].cpu().numpy(), rp)
