@@ -207,6 +207,25 @@ def test_config4_batch64_two_batches_in_flight(dev):
             np.testing.assert_array_equal(got[i]["proposed"][b].cpu().numpy(), rp)
 
 
+def test_config4_clustered_boxes_nms(dev):
+    """The bench's second NMS input at its full size: 64 images of 12,000 candidates in 40 tight
+    clusters (some 42 kept, every chunk walked) -- the case in which most of the mask kernel's
+    workgroups find nothing to do.  Keep lists of every image against the sequential NMS."""
+    from oracle import c_oracle
+    from objectdetection_amd import ops
+    import bench
+    cfg = _cfg1()
+    lib = c_oracle.load()
+    cl = bench.clustered_boxes(64, cfg.pre_k, dev, seed=77)
+    prop, keep, cnt = ops.nms(cl, cfg.nms_thr, cfg.post_n)
+    boxes = cl.cpu().numpy()
+    for b in range(64):
+        rp, rk, rc = c_oracle.nms(lib, boxes[b], cfg.nms_thr, cfg.post_n)
+        assert int(cnt[b]) == rc
+        np.testing.assert_array_equal(keep[b].cpu().numpy(), rk)
+        np.testing.assert_array_equal(prop[b].cpu().numpy(), rp)
+
+
 def test_config5_train_batch8_roi_backward_full_size(dev):
     """Config 5's path at its stated size: 8 images per GPU, 37x62x512 map, 2,000 RoIs:
     forward with the winner index, then the RoI backward.  One image's whole gradient map
