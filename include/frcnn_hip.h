@@ -14,7 +14,10 @@
  *   - feature maps are addressed through explicit element strides
  *     (sb, sh, sw, sc); channels-last (sc == 1) is the fast layout;
  *   - the caller owns inputs, outputs and workspace; the library allocates
- *     nothing, keeps no pointer and has no global state;
+ *     nothing and keeps no caller pointer.  Its only process-wide state: the
+ *     tuning values below (atomics; the environment is read once, when the
+ *     library is loaded -- no entry point calls getenv) and the scratch array
+ *     of frcnn_nms_static.  Every other entry point is re-entrant;
  *   - work is ordered on `stream` (a hipStream_t passed as void*); no call
  *     synchronises the device;
  *   - return value: FRCNN_OK or a negative FRCNN_E_* code; nothing throws.
@@ -51,6 +54,23 @@ typedef void* frcnn_stream_t;
 
 int         frcnn_abi_version(void);
 const char* frcnn_status_string(int status);
+
+/* Tuning values: thresholds that select between kernels computing the same result (no
+ * counterpart in the reference).  key is the short name or its environment variable:
+ *   "nms_gk"            FRCNN_NMS_GK            mask workgroups per column block (<= 0: by batch)
+ *   "roi_band_min_wg"   FRCNN_ROI_BAND_MIN_WG   band-resident RoI forward from n workgroups on and
+ *                                               for any RoI count (n < 0: never)
+ *   "bwd_cx"            FRCNN_BWD_CX            feature cells per wave of the gather backward (1|2)
+ *   "bwd_chunk"         FRCNN_BWD_CHUNK         RoIs per launch of the gather backward (<= 0: by batch)
+ *   "bwd_band"          FRCNN_BWD_BAND          band-owner RoI backward: 1 always (when the sizes
+ *                                               allow), 0 never
+ *   "nms_fused_max_b"   FRCNN_NMS_FUSED_MAX_B   single-launch NMS for batches up to n images
+ * A variable present in the environment when the library is loaded gives the initial value;
+ * frcnn_set_tuning replaces it (FRCNN_TUNING_UNSET restores the built-in choice).  Returns
+ * FRCNN_E_BADARG for an unknown key. */
+#define FRCNN_TUNING_UNSET ((long long)(-9223372036854775807LL - 1))
+int frcnn_set_tuning(const char* key, long long value);
+int frcnn_get_tuning(const char* key, long long* value);
 
 /* ---- a1: anchor grid -------------------------------------------------------
  * Replaces make_anchor(), Faster_RCNN/module/anchor.py:10-44 (31x31x9) and
@@ -183,7 +203,7 @@ int frcnn_roi_crop_pool_fwd(const float* fmap, int B, int H, int W, int C,
                             float* out, uint8_t* winner, frcnn_stream_t stream);
 
 /* The same forward with a caller-provided workspace of frcnn_roi_fwd_workspace_bytes(B,R) bytes
- * (272 per RoI, 16-byte aligned, contents on entry do not matter), for the band-resident
+ * (272 per RoI + a 16-byte header, 16-byte aligned, contents on entry do not matter), for the band-resident
  * kernel: a workgroup keeps a band of one image's feature rows for 32 channels in LDS and
  * serves every RoI of the image from there, so the feature map enters each compute unit once
  * instead of once per RoI (module/model.py:53-55 and :30 as above; same results bit for bit).
@@ -192,7 +212,7 @@ int frcnn_roi_crop_pool_fwd(const float* fmap, int B, int H, int W, int C,
  * most 16 x 16; every other call is forwarded to frcnn_roi_crop_pool_fwd, so the entry point
  * accepts whatever that one accepts.  On the 600x1000 workload (C = 512, R = 2000) the band
  * kernel takes 3.16 ms per 64 images against 4.0 ms for the per-RoI kernel, and loses below 16
- * images per call.  The environment variable FRCNN_ROI_BAND_MIN_WG = n replaces the workgroup
+ * images per call.  The tuning value "roi_band_min_wg" = n replaces the workgroup
  * threshold and lifts the RoI threshold (n < 0: never).  frcnn_roi_fwd_plan tells which kernel
  * a call with a channels-last, 16-byte aligned map and a full workspace would run (1: band,
  * 0: per RoI).
@@ -214,8 +234,11 @@ int frcnn_roi_crop_pool_fwd_ws(const float* fmap, int B, int H, int W, int C,
  * writes the per-RoI sample geometry into the workspace if a channels-last call of these
  * dimensions would run the band kernel (returns 1; 0: nothing to prepare; < 0: error), e.g. on the
  * stream that computed the proposals; frcnn_roi_crop_pool_fwd_prepared is frcnn_roi_crop_pool_fwd_ws
- * without that step (same arguments, same rois, ordered after the prepare call by the caller).
- * A planar map is transposed by the second call as before. */
+ * without that step (same arguments, same rois, ordered after the prepare call by the caller; call it
+ * only after prepare returned 1 for the same dimensions and winner choice).  The geometry carries a
+ * header with the dimensions it was made for: a band kernel that finds another header (a workspace
+ * prepare never wrote, or wrote for another call) returns without writing `out` rather than follow
+ * foreign descriptors.  A planar map is transposed by the second call as before. */
 int frcnn_roi_fwd_prepare(const float* rois, int B, int H, int W, int C, int R, int crop_h,
                           int crop_w, int pool, int want_winner, void* workspace,
                           size_t workspace_bytes, frcnn_stream_t stream);

@@ -41,6 +41,8 @@ _i64, _u64, _sz = C.c_int64, C.c_uint64, C.c_size_t
 _SIGS = {
     "frcnn_abi_version": (C.c_int, []),
     "frcnn_status_string": (C.c_char_p, [_i]),
+    "frcnn_set_tuning": (_i, [C.c_char_p, C.c_longlong]),
+    "frcnn_get_tuning": (_i, [C.c_char_p, C.POINTER(C.c_longlong)]),
     "frcnn_anchors": (_i, [_p, _i, _i, C.POINTER(_d), _i, C.POINTER(_d), _i, _d, _d, _p]),
     "frcnn_iou_assign": (_i, [_p, _i, _p, _i, _i, _f, _f, _p, _p, _p, _p, _p]),
     "frcnn_rpn_sample": (_i, [_p, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _u64, _i, _i, _i,
@@ -81,6 +83,21 @@ for _name, (_res, _args) in _SIGS.items():
     _fn.argtypes = _args
 
 EXPORTS = tuple(_SIGS)
+
+
+TUNING_UNSET = -(1 << 63)
+
+
+def set_tuning(key: str, value=None) -> None:
+    """frcnn_set_tuning: value None restores the built-in choice."""
+    check("frcnn_set_tuning", lib.frcnn_set_tuning(key.encode(), TUNING_UNSET if value is None
+                                                   else int(value)))
+
+
+def get_tuning(key: str):
+    v = C.c_longlong(0)
+    check("frcnn_get_tuning", lib.frcnn_get_tuning(key.encode(), C.byref(v)))
+    return None if v.value == TUNING_UNSET else v.value
 
 
 def status_string(status: int) -> str:

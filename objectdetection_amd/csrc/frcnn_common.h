@@ -27,6 +27,21 @@
 
 namespace frcnn {
 
+// Host-side tuning values (kernel selection thresholds).  Each is read from its environment
+// variable ONCE, when the library is loaded, and can be replaced afterwards with
+// frcnn_set_tuning(); entry points read the stored value (an atomic), never the environment.
+enum Tuning {
+    TUNE_NMS_GK = 0,          // FRCNN_NMS_GK: mask workgroups per column block (0 = by batch size)
+    TUNE_ROI_BAND_MIN_WG,     // FRCNN_ROI_BAND_MIN_WG: band kernel from n workgroups on (< 0: never)
+    TUNE_BWD_CX,              // FRCNN_BWD_CX: feature cells per wave of the gather backward (1 | 2)
+    TUNE_BWD_CHUNK,           // FRCNN_BWD_CHUNK: RoIs per backward launch (0 = by batch size)
+    TUNE_BWD_BAND,            // FRCNN_BWD_BAND: band-owner backward (1 on, 0 off, unset = by size)
+    TUNE_NMS_FUSED_MAX_B,     // FRCNN_NMS_FUSED_MAX_B: one-launch NMS up to this many images
+    TUNE_COUNT
+};
+constexpr long long TUNE_UNSET = (long long)0x8000000000000000ull;
+long long tuning(Tuning t);                       // TUNE_UNSET when neither set nor in the environment
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 

@@ -2,7 +2,6 @@
 // sort, fused box decode) and greedy NMS (wave-ballot bitmask kernel followed
 // by a one-wave scan per image).  gfx950, wave64.  -ffp-contract=off.
 #include "frcnn_common.h"
-#include <cstdlib>
 #include <atomic>
 
 namespace frcnn {
@@ -475,7 +474,7 @@ static int nms_launch(const float* boxes, int B, int K, float iou_threshold, int
     // workgroups per column block for the kept row tiles: one per tile with few images (every
     // tile in parallel), fewer -- each taking several tiles in turn -- with many
     int gk = (16384 + NMS_CW * B - 1) / (NMS_CW * B);
-    if (const char* e = getenv("FRCNN_NMS_GK")) gk = atoi(e);
+    if (const long long t = tuning(TUNE_NMS_GK); t != TUNE_UNSET && t > 0) gk = (int)(t < 65536 ? t : 65536);
     gk = gk < 1 ? 1 : gk > KT ? KT : gk;
     if ((long long)B * (1 + NMS_TRI_WGS) > 0x7FFFFFFFll) return FRCNN_E_UNSUPPORTED;
     for (int cb0 = 0, ci = 0; cb0 < CB; cb0 += NMS_CW, ++ci) {

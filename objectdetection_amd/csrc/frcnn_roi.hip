@@ -677,7 +677,12 @@ __device__ __forceinline__ void staged_walk_hot(const StageCtx& c, const RowDup&
     };
     auto step = [&](int j, auto slot_c, Quad (&hc)[NS], const Quad (&hp)[NS]) {
         constexpr int slot = decltype(slot_c)::value;
-        wait_vm_zero_or<NQ * (WIN ? 2 : 1)>(issued - mark[slot]);   // row j has landed in its slot
+        // Row j has landed in its slot.  With two slots the only vector-memory operations issued
+        // between a row's staging and its read are output-row stores, so a non-zero count is at
+        // least one row's stores; with more slots later rows' staging loads (1..4 pieces) sit in
+        // between and only the exact count is safe.
+        if constexpr (ST_NSLOT == 2) wait_vm_zero_or<NQ * (WIN ? 2 : 1)>(issued - mark[slot]);
+        else                         wait_vm_at_most(issued - mark[slot]);
         const unsigned char* sp = c.ring + slot * ST_SLOT_BYTES;
         Quad cl[NS], cr[NS];
 #pragma unroll
@@ -1378,7 +1383,7 @@ extern "C" int frcnn_roi_crop_pool_bwd(const float* dY, const uint8_t* winner, c
         // cells per wave: two neighbours of a row share the pairs they fetch (B = 64: 12.4 ms
         // against 14.3 ms with one cell per wave; B = 8: 2.09 against 2.14)
         int cx = 2;
-        if (const char* e = getenv("FRCNN_BWD_CX")) cx = atoi(e) == 1 ? 1 : 2;
+        if (tuning(TUNE_BWD_CX) == 1) cx = 1;
         const long long nwave = (long long)H * ((W + cx - 1) / cx) * B * nsl;
         if (nwave > 0x7FFFFFF0ll) return FRCNN_E_UNSUPPORTED;
         const dim3 cgrid((unsigned)nwave);
@@ -1387,7 +1392,7 @@ extern "C" int frcnn_roi_crop_pool_bwd(const float* dY, const uint8_t* winner, c
         // the L2 when the next wave asks.  B = 64: 11.1 ms at 512, 11.3 at 256, 12.2 in one
         // launch; B = 8 has too few waves to fill the chip twice and is best in one launch.
         int chunk = B >= 32 ? 512 : R;
-        if (const char* e = getenv("FRCNN_BWD_CHUNK")) chunk = atoi(e);
+        if (const long long t = tuning(TUNE_BWD_CHUNK); t != TUNE_UNSET && t > 0) chunk = (int)(t < R ? t : R);
         if (chunk <= 0 || chunk > R) chunk = R;
         chunk = (chunk + 63) / 64 * 64;
 #define FRCNN_BWD(P, Q)                                                                          \

@@ -36,7 +36,6 @@
 // out = top + (bottom-top)*ly; first maximum wins).  gfx950, wave64, -ffp-contract=off.
 #include "frcnn_common.h"
 #include <cstddef>
-#include <cstdlib>
 
 namespace frcnn {
 
@@ -66,11 +65,31 @@ struct RoiDesc { uint32_t y[2 * BD_MAXCROP]; uint32_t x[2 * BD_MAXCROP]; uint32_
 static_assert(sizeof(RoiDesc) == 272 && sizeof(RoiDesc) % 16 == 0, "descriptor layout");
 static_assert(offsetof(RoiDesc, band) == BD_ENTRY, "ring entries are the y and x parts");
 
+// Behind the descriptors the workspace carries a 16-byte header: a magic word and a key made of
+// every dimension the descriptors depend on.  The geometry kernel writes it, the band kernel
+// compares it with the key of its own launch and returns without reading a descriptor when they
+// differ (descriptors of another call, or never written: their row / column words would
+// otherwise become wild addresses).
+constexpr uint32_t BD_MAGIC = 0x42444831u;
+struct BandHeader { uint32_t magic, key, pad0, pad1; };
+
+static uint32_t band_key(int B, int R, int H, int W, int ch, int cw, int pool, int nb, int S, int T) {
+    const int v[10] = {B, R, H, W, ch, cw, pool, nb, S, T};
+    uint32_t h = 2166136261u;                    // FNV-1a over the ten values
+    for (int i = 0; i < 10; ++i)
+        for (int k = 0; k < 4; ++k) { h ^= ((uint32_t)v[i] >> (8 * k)) & 0xFFu; h *= 16777619u; }
+    return h;
+}
+
 __global__ void __launch_bounds__(256)
 roi_band_prep_kernel(const float4* __restrict__ rois, int n_roi, int H, int W, int ch, int cw,
-                     int pool, int nb, int S, int T, RoiDesc* __restrict__ desc) {
+                     int pool, int nb, int S, int T, RoiDesc* __restrict__ desc, uint32_t key) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_roi) return;
+    if (i == 0) {
+        BandHeader* h = reinterpret_cast<BandHeader*>(desc + n_roi);
+        h->magic = BD_MAGIC; h->key = key; h->pad0 = 0u; h->pad1 = 0u;
+    }
     const float4 box = rois[i];
     RoiDesc* d = desc + i;
     // pass 1: the band of every output row
@@ -295,8 +314,13 @@ __global__ void __launch_bounds__(64 * BD_WAVES) __attribute__((amdgpu_waves_per
 roi_fwd_band_kernel(const float* __restrict__ fmap, int H, int W, int C, long long sb, long long sh,
                     long long sw, const RoiDesc* __restrict__ desc, int R, int ch, int cw,
                     int ngroup, int nband, int nimg, int S, int T, float* __restrict__ out,
-                    uint8_t* __restrict__ winner) {
+                    uint8_t* __restrict__ winner, uint32_t key) {
     extern __shared__ __attribute__((aligned(16))) unsigned char band_lds[];
+    {
+        // the descriptors must be those of a call with these very dimensions (uniform: a scalar load)
+        const BandHeader* h = reinterpret_cast<const BandHeader*>(desc + (size_t)nimg * R);
+        if (h->magic != BD_MAGIC || h->key != key) return;
+    }
     // Workgroup n runs on XCD n % 8 (each XCD has its own L2).  The ngroup channel groups of one
     // (image, band) are given to one XCD at consecutive times: that L2 then sees all the 128-byte
     // pieces of an output bin (and of a descriptor) instead of an eighth of them.
@@ -633,7 +657,7 @@ static size_t roi_ws_align(size_t v) { return (v + 255) & ~(size_t)255; }
 
 extern "C" size_t frcnn_roi_fwd_workspace_bytes(int B, int R) {
     if (B <= 0 || R <= 0) return 0;
-    return roi_ws_align((size_t)B * R * sizeof(RoiDesc));
+    return roi_ws_align((size_t)B * R * sizeof(RoiDesc) + sizeof(BandHeader));
 }
 
 // Which forward kernel a channels-last call is given (alignment and workspace aside).
@@ -649,7 +673,7 @@ static bool band_wanted(int B, int H, int W, int C, int R, int crop_h, int crop_
     const BandPlan plan = band_plan(H, W, crop_h, pool);
     long long min_wg = 768;
     int min_roi = 1024;
-    if (const char* e = getenv("FRCNN_ROI_BAND_MIN_WG")) { min_wg = atoll(e); min_roi = 1; }
+    if (const long long t = tuning(TUNE_ROI_BAND_MIN_WG); t != TUNE_UNSET) { min_wg = t; min_roi = 1; }
     return plan.ok && plan.nb < (int)BD_NONE && crop_h <= BD_MAXCROP && crop_w <= BD_MAXCROP && H < 4096 && W < 4096 &&
            min_wg >= 0 && (long long)B * (C / BD_CG) * plan.nb >= min_wg &&
            (long long)B * (C / BD_CG) * plan.nb <= 0x7FFFFFFFll && R >= min_roi &&
@@ -678,7 +702,8 @@ static int launch_band_prep(const float* rois, int B, int H, int W, int R, int c
     const int n_roi = B * R;
     FRCNN_LAUNCH(roi_band_prep_kernel, dim3((n_roi + 255) / 256), dim3(256), 0, st,
                  reinterpret_cast<const float4*>(rois), n_roi, H, W, crop_h, crop_w, pool, plan.nb,
-                 plan.S, plan.T, reinterpret_cast<RoiDesc*>(workspace));
+                 plan.S, plan.T, reinterpret_cast<RoiDesc*>(workspace),
+                 band_key(B, R, H, W, crop_h, crop_w, pool, plan.nb, plan.S, plan.T));
     return FRCNN_OK;
 }
 
@@ -745,6 +770,7 @@ static int roi_fwd_ws_impl(const float* fmap, int B, int H, int W, int C, int64_
     }
     const size_t lds = (size_t)plan.T * W * BD_CELL + BD_LDS_RING + 64;    // + the claim counter
     const dim3 grid((unsigned)((long long)ngroup * plan.nb * B)), block(64 * BD_WAVES);
+    const uint32_t key = band_key(B, R, H, W, crop_h, crop_w, pool, plan.nb, plan.S, plan.T);
 #define FRCNN_BAND(P, WN)                                                                          \
     do {                                                                                           \
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(roi_fwd_band_kernel<P, WN>),         \
@@ -752,7 +778,7 @@ static int roi_fwd_ws_impl(const float* fmap, int B, int H, int W, int C, int64_
             return FRCNN_E_LAUNCH;                                                                 \
         FRCNN_LAUNCH((roi_fwd_band_kernel<P, WN>), grid, block, lds, st, fmap, H, W, C,            \
                      (long long)sb, (long long)sh, (long long)sw, desc, R, crop_h, crop_w, ngroup, plan.nb, B, \
-                     plan.S, plan.T, out, winner);                                                 \
+                     plan.S, plan.T, out, winner, key);                                            \
     } while (0)
     if (pool == 2) { if (winner) FRCNN_BAND(2, true); else FRCNN_BAND(2, false); }
     else           { FRCNN_BAND(1, false); }

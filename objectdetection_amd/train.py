@@ -178,7 +178,7 @@ class GradBuckets:
     def _close(self, ps):
         n = sum(p.numel() for p in ps)
         flat = torch.zeros(n, dtype=ps[0].dtype, device=ps[0].device)
-        b = dict(flat=flat, n=len(ps), ready=0)
+        b = dict(flat=flat, n=len(ps), ready=0, launched=False)
         off = 0
         for p in ps:
             p.grad = flat[off:off + p.numel()].view_as(p)
@@ -188,7 +188,12 @@ class GradBuckets:
 
     def _ready(self, b):
         b["ready"] += 1
-        if b["ready"] == b["n"] and self.dist is not None:
+        if b["ready"] == b["n"]:
+            self._launch(b)
+
+    def _launch(self, b):
+        b["launched"] = True
+        if self.dist is not None:
             self.handles.append(self.dist.all_reduce(b["flat"], op=self.dist.ReduceOp.SUM,
                                                      async_op=True))
 
@@ -196,9 +201,17 @@ class GradBuckets:
         for b in self.buckets:
             b["flat"].zero_()
             b["ready"] = 0
+            b["launched"] = False
         self.handles = []
 
     def finish(self):
+        """Waits for the all-reduces.  A bucket with a parameter that received no gradient in
+        this step (a frozen or unused layer) never fills: it is reduced here, zeros included, in
+        bucket order -- every rank has the same parameters, so every rank issues the same
+        collectives in the same order."""
+        for b in self.buckets:
+            if not b["launched"]:
+                self._launch(b)
         for h in self.handles:
             h.wait()
         self.handles = []
@@ -219,7 +232,11 @@ class TrainStep:
         self.rank, self.world, self.roi_grad = rank, world, roi_grad
         params = list(rpn.parameters()) + list(frcn.parameters())
         self.buckets = GradBuckets(params, self.dist, bucket_bytes)
-        self.opt = torch.optim.Adam(params, lr=lr)          # model_train.py:590
+        # model_train.py:590.  The reference applies the RPN and the head gradients with two
+        # apply_gradients calls on ONE Adam per iteration (:661-664), so its step counter (bias
+        # correction) advances by two per iteration; here one opt.step() advances it by one.
+        # Per-parameter moments are the same (each variable is updated once per iteration).
+        self.opt = torch.optim.Adam(params, lr=lr)
 
     def _global(self, t: torch.Tensor) -> torch.Tensor:
         """Sum of a small device tensor over the ranks (stays on the device: no host sync)."""

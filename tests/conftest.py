@@ -33,3 +33,19 @@ def pytest_collection_modifyitems(config, items):
 def dev():
     import torch
     return torch.device("cuda:0")
+
+
+@pytest.fixture
+def tuning():
+    """Set library tuning values (frcnn_set_tuning) for one test; restored afterwards."""
+    from objectdetection_amd import _lib
+    saved = {}
+
+    def set_(key, value):
+        if key not in saved:
+            saved[key] = _lib.get_tuning(key)
+        _lib.set_tuning(key, value)
+
+    yield set_
+    for key, value in saved.items():
+        _lib.set_tuning(key, value)

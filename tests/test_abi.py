@@ -56,13 +56,42 @@ def test_bad_arguments_are_rejected_without_a_gpu():
                               one, one, one, one, one, one, one, None) == _lib.E_BADARG
 
 
-def test_roi_forward_plan_and_prepare_argument_checks(monkeypatch):
+def test_tuning_values_are_stored_not_read_from_the_environment(monkeypatch):
+    """The environment is read once, when the library is loaded: a variable set afterwards changes
+    nothing, frcnn_set_tuning does, and unknown keys are rejected."""
+    from objectdetection_amd import _lib
+    L = _lib.lib
+    before = _lib.get_tuning("roi_band_min_wg")
+    monkeypatch.setenv("FRCNN_ROI_BAND_MIN_WG", "-1")
+    assert _lib.get_tuning("roi_band_min_wg") == before
+    assert L.frcnn_roi_fwd_plan(64, 37, 62, 512, 2000, 14, 14, 2, 0) == (1 if before is None else
+                                                                         int(before >= 0))
+    _lib.set_tuning("FRCNN_NMS_GK", 7)                 # the variable's name works as a key too
+    assert _lib.get_tuning("nms_gk") == 7
+    _lib.set_tuning("nms_gk", None)
+    assert _lib.get_tuning("nms_gk") is None
+    assert L.frcnn_set_tuning(b"no_such_key", 1) == _lib.E_BADARG
+    assert L.frcnn_get_tuning(b"nms_gk", None) == _lib.E_BADARG
+
+
+def test_no_entry_point_reads_the_environment():
+    """getenv appears in one place only: the static initialiser of the tuning table."""
+    import glob
+    for f in glob.glob(os.path.join(ROOT, "objectdetection_amd", "csrc", "*.hip")):
+        src = re.sub(r"//.*", "", open(f).read())
+        if os.path.basename(f) != "frcnn_abi.hip":
+            assert "getenv" not in src, f
+        else:
+            assert src.count("getenv(") == 1
+
+
+def test_roi_forward_plan_and_prepare_argument_checks():
     """Which RoI forward kernel a call gets is host logic (no launch): the band-resident kernel
     from 768 workgroups (B * C/32 * bands) and 1,024 RoIs per image on, the per-RoI one below;
-    FRCNN_ROI_BAND_MIN_WG moves the threshold."""
+    the tuning value roi_band_min_wg moves the threshold."""
     from objectdetection_amd import _lib, ops
     L = _lib.lib
-    monkeypatch.delenv("FRCNN_ROI_BAND_MIN_WG", raising=False)
+    _lib.set_tuning("roi_band_min_wg", None)
     assert L.frcnn_roi_fwd_plan(64, 37, 62, 512, 2000, 14, 14, 2, 0) == 1      # 64 x 16 x 3 bands
     assert L.frcnn_roi_fwd_plan(16, 37, 62, 512, 2000, 14, 14, 2, 1) == 1      # 768 workgroups
     assert L.frcnn_roi_fwd_plan(15, 37, 62, 512, 2000, 14, 14, 2, 0) == 0
@@ -74,13 +103,14 @@ def test_roi_forward_plan_and_prepare_argument_checks(monkeypatch):
     assert L.frcnn_roi_fwd_plan(0, 37, 62, 512, 2000, 14, 14, 2, 0) == 0
     assert ops.roi_fwd_kernel_name(64, 37, 62, 512, 2000, (14, 14), 2) == "roi_fwd_band_kernel<2,false>"
     assert ops.roi_fwd_kernel_name(8, 37, 62, 512, 2000, (14, 14), 2, True) == "roi_fwd_stage_kernel<2,true>"
-    monkeypatch.setenv("FRCNN_ROI_BAND_MIN_WG", "1")
+    _lib.set_tuning("roi_band_min_wg", 1)
     assert L.frcnn_roi_fwd_plan(1, 9, 11, 64, 30, 14, 14, 2, 0) == 1
-    monkeypatch.setenv("FRCNN_ROI_BAND_MIN_WG", "-1")
+    _lib.set_tuning("roi_band_min_wg", -1)
     assert L.frcnn_roi_fwd_plan(64, 37, 62, 512, 2000, 14, 14, 2, 0) == 0
-    monkeypatch.delenv("FRCNN_ROI_BAND_MIN_WG")
+    _lib.set_tuning("roi_band_min_wg", None)
     one = ctypes.c_void_p(16)
-    assert L.frcnn_roi_fwd_workspace_bytes(64, 2000) == 64 * 2000 * 272
+    # 272 bytes per RoI + the 16-byte header, rounded up to 256
+    assert L.frcnn_roi_fwd_workspace_bytes(64, 2000) == (64 * 2000 * 272 + 16 + 255) // 256 * 256
     assert L.frcnn_roi_fwd_prepare(None, 64, 37, 62, 512, 2000, 14, 14, 2, 0, one, 1 << 30, None) == _lib.E_BADARG
     # nothing to prepare: small call, missing or short workspace (no launch in any of these)
     assert L.frcnn_roi_fwd_prepare(one, 8, 37, 62, 512, 2000, 14, 14, 2, 0, one, 1 << 30, None) == 0

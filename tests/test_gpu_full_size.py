@@ -134,7 +134,7 @@ def test_config3_dense_100k_nms(dev):
     assert int(cnt2[0]) == rc[0]
 
 
-def test_config3_assign_and_labels_g200(dev):
+def test_config3_anchor_assignment_g200(dev):
     from objectdetection_amd import ops
     H, W = 50, 83
     scales, ratios = (64, 128, 256, 384, 512), (0.5, 1, 2)
@@ -151,6 +151,90 @@ def test_config3_assign_and_labels_g200(dev):
     ref = O.patch_batch(dict(image=None, bbox=d["gt"][0], label=d["label"][0]), a, seed=3)
     np.testing.assert_array_equal(out["pos"][0].cpu().numpy(), ref[5])
     np.testing.assert_array_equal(out["gt_list"][0].cpu().numpy(), ref[4])
+
+
+def test_config3_whole_path_50x83x15_g200(dev):
+    """Config 3's map at its stated size inside the path: 1333x800 -> 50x83x15 = 62,250 anchors,
+    G = 200, top-12,000 of 62,250 (the radix-sort top-k at that N), NMS -> 2,000, RoI crop + pool
+    on the 50x83x512 map (four bands of rows), proposal labels and head sampling at G = 200."""
+    from oracle import c_oracle
+    from objectdetection_amd.config import PathConfig
+    from objectdetection_amd.pipeline import RegionProposalPath
+    cfg = PathConfig(H=50, W=83, scales=(64, 128, 256, 384, 512), ratios=(0.5, 1, 2),
+                     base_w=1333.0, base_h=800.0, G=200, pre_k=12000, post_n=2000)
+    assert cfg.N == 62250
+    B, C = 2, 512
+    lib = c_oracle.load()
+    d = O.synth_inputs(seed=33, B=B, H=cfg.H, W=cfg.W, A=cfg.A, C=C, G=cfg.G, n_gt=200)
+    for topk in ("sort", "lds"):
+        path = RegionProposalPath(cfg, B, C, dev, train=True, want_winner=True, topk=topk)
+        path.run(T(d["fmap"], dev), T(d["score"], dev), T(d["coord"], dev), T(d["gt"], dev),
+                 T(d["label"], dev), seed=6)
+        _, ri = O.top_k(d["score"].reshape(B, -1), cfg.pre_k)
+        np.testing.assert_array_equal(path.top_idx.cpu().numpy(), ri)
+        cand = path.cand.cpu().numpy()
+        prop = path.proposed.cpu().numpy()
+        for b in range(B):
+            rp, rk, rc = c_oracle.nms(lib, cand[b], cfg.nms_thr, cfg.post_n)
+            np.testing.assert_array_equal(path.keep_pos[b].cpu().numpy(), rk)
+            np.testing.assert_array_equal(prop[b], rp)
+        lab = O.label_proposals(prop, d["gt"], d["label"])
+        np.testing.assert_array_equal(path.p_label.cpu().numpy(), lab["p_iou"])
+        np.testing.assert_array_equal(path.p_best.cpu().numpy(), lab["best"])
+        np.testing.assert_array_equal(path.p_iou.cpu().numpy(), lab["max_iou"])
+        np.testing.assert_array_equal(path.gt_mask.cpu().numpy(), lab["gt_mask"])
+        assert (lab["p_iou"] != cfg.bg_label).sum() > 0
+        np.testing.assert_array_equal(path.tindex.cpu().numpy(), O.sample_proposals(lab["p_iou"], seed=6))
+        ro, ra = c_oracle.roi_crop_pool(lib, d["fmap"][1], prop[1], cfg.crop, cfg.pool)
+        np.testing.assert_array_equal(path.pooled[1].cpu().numpy(), ro)
+        np.testing.assert_array_equal(path.winner[1].cpu().numpy(), ra)
+        del path
+    # the band-resident kernel on the same map (it is chosen from 768 workgroups on: B = 12 here)
+    from objectdetection_amd import ops
+    Bb = 12
+    assert ops.roi_fwd_kernel_name(Bb, cfg.H, cfg.W, C, cfg.post_n, cfg.crop, cfg.pool).startswith(
+        "roi_fwd_band")
+    fm = torch.relu(torch.randn((Bb, cfg.H, cfg.W, C), device=dev,
+                                generator=torch.Generator(device=dev).manual_seed(3)))
+    rois = T(prop[:1], dev).expand(Bb, -1, -1).contiguous()
+    ws = torch.empty(ops.roi_fwd_workspace_bytes(Bb, cfg.post_n), dtype=torch.uint8, device=dev)
+    out, _ = ops.roi_crop_pool_fwd(fm, rois, cfg.crop, cfg.pool, workspace=ws)
+    for b in (0, 11):
+        ro, _ = c_oracle.roi_crop_pool(lib, fm[b].cpu().numpy(), prop[0], cfg.crop, cfg.pool,
+                                       want_winner=False)
+        np.testing.assert_array_equal(out[b].cpu().numpy(), ro)
+
+
+def test_config2_ship_batch16_c512_band_kernel(dev):
+    """Config 2 at the bench's own size: 16 ship images, 48x48x12 anchors, C = 512 -- the
+    band-resident RoI kernel on the 48x48x512 map.  Pooled tensor of two images against the C
+    oracle, keep lists of the same two against the sequential NMS."""
+    from oracle import c_oracle
+    from objectdetection_amd import ops
+    from objectdetection_amd.pipeline import RegionProposalPath
+    import bench
+    cfg = bench.workload_cfg("ship768")
+    B, C = 16, 512
+    assert ops.roi_fwd_kernel_name(B, cfg.H, cfg.W, C, cfg.post_n, cfg.crop, cfg.pool) == \
+        "roi_fwd_band_kernel<2,false>"
+    lib = c_oracle.load()
+    f, s, c, g, l = bench.make_inputs(cfg, B, C, dev, seed=2202, gt_side=(0.01, 0.06))
+    path = RegionProposalPath(cfg, B, C, dev, train=True, depth=2)
+    ready = torch.cuda.Event()
+    ready.record(torch.cuda.current_stream(dev))
+    path.run(f, s, c, g, l, seed=1, inputs_ready=ready)
+    torch.cuda.synchronize()
+    cand, prop = path.cand.cpu().numpy(), path.proposed.cpu().numpy()
+    for b in (2, 13):
+        rp, rk, rc = c_oracle.nms(lib, cand[b], cfg.nms_thr, cfg.post_n)
+        np.testing.assert_array_equal(path.keep_pos[b].cpu().numpy(), rk)
+        np.testing.assert_array_equal(prop[b], rp)
+        ro, _ = c_oracle.roi_crop_pool(lib, f[b].cpu().numpy(), prop[b], cfg.crop, cfg.pool,
+                                       want_winner=False)
+        np.testing.assert_array_equal(path.pooled[b].cpu().numpy(), ro)
+    lab = O.label_proposals(prop, g.cpu().numpy(), l.cpu().numpy())
+    np.testing.assert_array_equal(path.p_label.cpu().numpy(), lab["p_iou"])
+    np.testing.assert_array_equal(path.tindex.cpu().numpy(), O.sample_proposals(lab["p_iou"], seed=1))
 
 
 def _cfg1():

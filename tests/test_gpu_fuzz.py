@@ -132,12 +132,12 @@ def test_fuzz_nms(seed, B, K, post_n, thr, mode):
 
 @pytest.mark.parametrize("gk", [1, 2, 3, 5])
 @pytest.mark.parametrize("mode", ["uniform", "clustered", "degenerate"])
-def test_nms_kept_tiles_shared_with_a_stride(gk, mode, monkeypatch):
+def test_nms_kept_tiles_shared_with_a_stride(gk, mode, tuning):
     """With many images a mask workgroup takes several kept tiles of a column block in turn
     (stride gk); forced here on a small batch, with enough kept boxes for several tiles and
     candidates beyond the second chunk."""
     from objectdetection_amd import ops
-    monkeypatch.setenv("FRCNN_NMS_GK", str(gk))
+    tuning("nms_gk", gk)
     rng = np.random.default_rng(100 + gk)
     B, K, post_n, thr = 3, 2600, 700, 0.7
     boxes = np.stack([np.clip(draw_boxes(rng, K, mode), 0, 1) for _ in range(B)])
@@ -200,17 +200,15 @@ def test_fuzz_roi_forward_band_kernel(seed, B, H, W, C, R, cp, mode, prepared):
     fm = rng.standard_normal((B, H, W, C)).astype(np.float32)
     prop = np.stack([draw_boxes(rng, R, mode) for _ in range(B)])
     ws = torch.empty(ops.roi_fwd_workspace_bytes(B, R), dtype=torch.uint8, device=DEV)
-    old = os.environ.get("FRCNN_ROI_BAND_MIN_WG")
-    os.environ["FRCNN_ROI_BAND_MIN_WG"] = "1"
+    from objectdetection_amd import _lib
+    old = _lib.get_tuning("roi_band_min_wg")
+    _lib.set_tuning("roi_band_min_wg", 1)
     try:
         ready = prepared and ops.roi_fwd_prepare(T(prop), fm.shape, crop, pool, pool > 1, ws)
         out, win = ops.roi_crop_pool_fwd(T(fm), T(prop), crop, pool, want_winner=pool > 1,
                                          workspace=ws, prepared=ready)
     finally:
-        if old is None:
-            del os.environ["FRCNN_ROI_BAND_MIN_WG"]
-        else:
-            os.environ["FRCNN_ROI_BAND_MIN_WG"] = old
+        _lib.set_tuning("roi_band_min_wg", old)
     ro, ra = O.roi_crop_pool(fm, prop, crop, pool)
     np.testing.assert_array_equal(out.cpu().numpy(), ro)
     if pool > 1:

@@ -242,13 +242,14 @@ def test_roi_backward_exact_shapes(dev, C, pool, crop, R):
 
 
 @pytest.mark.parametrize("chunk,cx", [("64", "2"), ("128", "1"), ("64", "1")])
-def test_roi_backward_in_ranges_of_rois(dev, chunk, cx, monkeypatch):
+def test_roi_backward_in_ranges_of_rois(dev, chunk, cx, tuning):
     """From 32 images the backward is launched per range of RoIs (later ranges continue the
     earlier sums), and a wave may own one cell instead of two: both forced here on a small
     batch; the sums must not depend on either."""
     from objectdetection_amd import ops
-    monkeypatch.setenv("FRCNN_BWD_CHUNK", chunk)
-    monkeypatch.setenv("FRCNN_BWD_CX", cx)
+    tuning("bwd_chunk", int(chunk))
+    tuning("bwd_cx", int(cx))
+    tuning("bwd_band", 0)
     rng = np.random.default_rng(int(chunk) + int(cx))
     B, H, W, C, R = 2, 11, 15, 192, 150
     fm = np.maximum(rng.standard_normal((B, H, W, C)).astype(np.float32), 0)

@@ -75,12 +75,12 @@ class _Path:
 
 
 @pytest.fixture(params=["per_roi", "band", "band_prepared", "planar"])
-def ws_for(request, monkeypatch):
+def ws_for(request, tuning):
     """The forward entry points: frcnn_roi_crop_pool_fwd (one wave per RoI and slice),
     frcnn_roi_crop_pool_fwd_ws with its band kernel forced on at test sizes, and the same entry
     point on a planar [B,C,H,W] map (transposed into the workspace, then the per-RoI kernel)."""
     if request.param in ("band", "band_prepared"):     # the two-call form: prepare, then run
-        monkeypatch.setenv("FRCNN_ROI_BAND_MIN_WG", "1")
+        tuning("roi_band_min_wg", 1)
     return _Path(request.param)
 
 
@@ -158,12 +158,12 @@ def test_store_data_survives_the_next_row(dev):
 
 
 @pytest.mark.parametrize("B", [3, 5, 11])
-def test_band_kernel_workgroup_order(dev, monkeypatch, B):
+def test_band_kernel_workgroup_order(dev, tuning, B):
     """(image, band) pairs are dealt to the 8 XCDs in rounds of eight; a count that is not a
     multiple of eight ends with pairs in plain order.  37x62 maps have three bands: B = 3, 5, 11
     give 9, 15 and 33 pairs."""
     from objectdetection_amd import ops
-    monkeypatch.setenv("FRCNN_ROI_BAND_MIN_WG", "1")
+    tuning("roi_band_min_wg", 1)
     lib = c_oracle.load()
     rng = np.random.default_rng(B)
     H, W, C, R = 37, 62, 64, 60

@@ -184,6 +184,92 @@ def test_grad_buckets_are_views_and_zeroing_keeps_them():
     assert lin.bias.grad.tolist() == [2.0] * 4
 
 
+class _RecordingDist:
+    """Stands in for torch.distributed in one process: records the buffers it is asked to sum."""
+
+    class ReduceOp:
+        SUM = "sum"
+
+    class _Done:
+        def wait(self):
+            pass
+
+    def __init__(self):
+        self.calls = []
+
+    def all_reduce(self, t, op=None, async_op=False):
+        self.calls.append(t.data_ptr())
+        return self._Done()
+
+
+def test_a_bucket_with_an_unused_parameter_is_still_reduced():
+    """A parameter that receives no gradient leaves its bucket short of its count; finish() must
+    reduce that bucket all the same (in bucket order), or the ranks would step on different
+    gradients without any error."""
+    a, b = torch.nn.Linear(8, 4), torch.nn.Linear(8, 4)          # b takes no part in the loss
+    d = _RecordingDist()
+    gb = GradBuckets(list(a.parameters()) + list(b.parameters()), d, bucket_bytes=1)
+    assert len(gb.buckets) == 4
+    gb.zero()
+    a(torch.ones(2, 8)).sum().backward()
+    assert len(d.calls) == 2                                    # a's two buckets, from the hooks
+    gb.finish()
+    assert sorted(d.calls) == sorted(bk["flat"].data_ptr() for bk in gb.buckets)
+    assert d.calls[2:] == [bk["flat"].data_ptr() for bk in gb.buckets if bk["ready"] != bk["n"]]
+    d.calls.clear()
+    gb.zero()
+    (a(torch.ones(2, 8)).sum() + b(torch.ones(2, 8)).sum()).backward()
+    gb.finish()
+    assert len(d.calls) == 4                                    # nothing is reduced twice
+
+
+def _worker_hip(rank, world, port, out_dir, per_rank):
+    """One rank of the HIP-backed training step; the ranks share cuda:0 and talk over gloo."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from objectdetection_amd.train import HipPathOps
+        dev = torch.device("cuda:0")
+        rpn, frcn = _models()
+        rpn, frcn = rpn.to(dev), frcn.to(dev)
+        images, gt, label = _data(world * per_rank)
+        sl = slice(rank * per_rank, (rank + 1) * per_rank)
+        step = TrainStep(rpn, frcn, CFG, HipPathOps(CFG, per_rank, rpn.channels, dev), dist, rank,
+                         world, bucket_bytes=64 << 10)
+        losses = step.forward_backward(images[sl].to(dev), gt[sl].to(dev), label[sl].to(dev), seed=4)
+        torch.cuda.synchronize()
+        if rank == 0:
+            torch.save(dict(grads=_grads(step).cpu(), losses=losses.cpu()),
+                       os.path.join(out_dir, "dp_hip.pt"))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_hip_step_two_ranks_give_the_one_rank_gradients(dev, tmp_path):
+    """The HIP-backed training step data parallel: two ranks (sharing the one GPU, gloo) with two
+    images each against one rank on the four images -- same sampled targets (counter keys follow
+    the global image index), global loss normalisation, bucketed gradient all-reduce."""
+    from objectdetection_amd.train import HipPathOps
+    world, per_rank = 2, 2
+    mp.spawn(_worker_hip, args=(world, _free_port(), str(tmp_path), per_rank), nprocs=world,
+             join=True)
+    got = torch.load(tmp_path / "dp_hip.pt", weights_only=True)
+    rpn, frcn = _models()
+    rpn, frcn = rpn.to(dev), frcn.to(dev)
+    images, gt, label = _data(world * per_rank)
+    step = TrainStep(rpn, frcn, CFG, HipPathOps(CFG, world * per_rank, rpn.channels, dev), None, 0,
+                     1, bucket_bytes=64 << 10)
+    losses = step.forward_backward(images.to(dev), gt.to(dev), label.to(dev), seed=4).cpu()
+    ref = _grads(step).cpu()
+    assert ref.abs().max() > 0
+    np.testing.assert_allclose(got["losses"].numpy(), losses.numpy(), rtol=1e-5)
+    np.testing.assert_allclose(got["grads"].numpy(), ref.numpy(), rtol=2e-4,
+                               atol=1e-6 * float(ref.abs().max()))
+
+
 @pytest.mark.gpu
 def test_hip_step_matches_the_oracle_backed_step(dev):
     """One step on the HIP path (RegionProposalPath, fused crop + pool with its backward, loss

@@ -5,7 +5,7 @@ TAG=${1:-band}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-export ROI_REPS=2 FRCNN_ROI_BAND_MIN_WG=1 ROI_BAND=1
+export ROI_REPS=2 FRCNN_ROI_BAND_MIN_WG=1 ROI_BAND=1   # read once, when the library is loaded
 i=0
 while read -r CTRS; do
   i=$((i+1))
