@@ -101,6 +101,151 @@ def algorithmic_bytes_roi(cfg, C, B):
     return per_image * B
 
 
+def sources_sha():
+    """Hash of the kernel sources the loaded library was built from (they travel with the tree):
+    counter-derived records under profiles/ carry the hash of the sources they were collected on
+    and are only quoted when it matches."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "objectdetection_amd", "csrc", "*.hip")) +
+                   glob.glob(os.path.join(ROOT, "objectdetection_amd", "csrc", "*.h")) +
+                   glob.glob(os.path.join(ROOT, "include", "*.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def profile_record(name):
+    """(record, note): a counter record under profiles/ if it was collected on these very kernel
+    sources, else (None, why not)."""
+    f = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(f):
+        return None, f"profiles/{name} is missing"
+    with open(f) as fh:
+        rec = json.load(fh)
+    have, want = rec.get("csrc_sha"), sources_sha()
+    if have != want:
+        return None, (f"profiles/{name} was collected on kernel sources {have}, this tree is "
+                      f"{want}: not quoted")
+    return rec, (f"profiles/{name}: collected by the builder with rocprofv3 --pmc on kernel sources "
+                 f"{have} (commit {rec.get('commit', '?')}), not measured in this run")
+
+
+def verify_against_oracle(path, cfg, fmap, image):
+    """Outside the timed region: one image of the last timed step against the CPU oracle (C
+    restatement): its keep list and proposals from the device's own candidate boxes, and its
+    whole pooled tensor from those proposals.  Bit-exact or SystemExit."""
+    from oracle import c_oracle
+    lib = c_oracle.load()
+    torch.cuda.synchronize()
+    cand = path.cand[image].cpu().numpy()
+    rp, rk, rc = c_oracle.nms(lib, cand, cfg.nms_thr, cfg.post_n)
+    if not (np.array_equal(path.keep_pos[image].cpu().numpy(), rk)
+            and np.array_equal(path.proposed[image].cpu().numpy(), rp)
+            and int(path.keep_count[image]) == int(rc)):
+        raise SystemExit(f"bench: keep list of image {image} differs from the oracle's greedy NMS")
+    ro, _ = c_oracle.roi_crop_pool(lib, fmap[image].cpu().numpy(), rp, cfg.crop, cfg.pool,
+                                   want_winner=False)
+    if not np.array_equal(path.pooled[image].cpu().numpy(), ro):
+        raise SystemExit(f"bench: pooled tensor of image {image} differs from the oracle's crop + pool")
+    return True
+
+
+def single_image(cfg, C, device, seed=4242):
+    """One image through the inference stages (the reference's per-epoch check runs one image,
+    model_train.py:741-743): whole-path latency as plain launches and as one HIP graph replay,
+    and the stages alone.  HIP events, idle chip, outside the timed region."""
+    from objectdetection_amd import ops
+    from objectdetection_amd.pipeline import RegionProposalPath
+    fmap, score, coord, _, _ = make_inputs(cfg, 1, C, device, seed=seed)
+    path = RegionProposalPath(cfg, 1, C, device, train=False, depth=1)
+    run = lambda: path.run(fmap, score, coord)
+    plain = timed_alone(run, device, reps=40, skip=10)
+    graph = path.capture(fmap, score, coord)
+    replay = timed_alone(graph.replay, device, reps=40, skip=10)
+    a = path.anchor.reshape(-1, 4)
+    topk_ms = timed_alone(lambda: ops.topk(score.reshape(1, -1), cfg.pre_k, a, coord, "sort",
+                                           workspace=path.topk_ws), device, reps=40, skip=10)
+    nms_ms = timed_alone(lambda: ops.nms(path.cand, cfg.nms_thr, cfg.post_n, workspace=path.nms_ws),
+                         device, reps=40, skip=10)
+    roi_ms = timed_alone(lambda: ops.roi_crop_pool_fwd(fmap, path.proposed, cfg.crop, cfg.pool,
+                                                       out=path.pooled, workspace=path.roi_ws),
+                         device, reps=40, skip=10)
+    return dict(latency_b1_ms=min(plain, replay), latency_b1_plain_launches_ms=plain,
+                latency_b1_graph_replay_ms=replay, topk_us_single_image=topk_ms * 1e3,
+                nms_us_single_image=nms_ms * 1e3, roi_us_single_image=roi_ms * 1e3,
+                kept=int(path.keep_count[0]),
+                note="one 600x1000 image, inference stages (top-k, NMS, RoI crop + pool), idle chip")
+
+
+def reference_api_step(cfg, B, C, device, fmap, score, coord, gt, label, anchor, steps, warmup):
+    """The same step through the reference's function names (patch_batch for the batch +
+    making_frcnn_input, objectdetection_amd/module): wall time per step with a host sync only at
+    both ends."""
+    from objectdetection_amd import pipeline
+    from objectdetection_amd.module import data as D
+    ready = torch.cuda.Event()
+    ready.record(torch.cuda.current_stream(device))
+
+    def step(k):
+        D.patch_batch_many(gt, anchor, cfg, seed=k, image_base=0)
+        D.making_frcnn_input(gt, label, fmap, coord, score, anchor, cfg, seed=k, fuse_pool=True,
+                             check=False, inputs_ready=ready)
+
+    for w in range(warmup):
+        step(w)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(100 + k)
+    torch.cuda.synchronize(device)
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    pipeline.clear_path_cache()
+    return ms
+
+
+def secondary_workload(name, C, device, steps, warmup, rank):
+    """A second workload's headline numbers (no CPU leg), same timing rules as the main line."""
+    from objectdetection_amd.pipeline import RegionProposalPath
+    wl, cfg = WORKLOADS[name], workload_cfg(name)
+    B = wl["batch"]
+    fmap, score, coord, gt, label = make_inputs(cfg, B, C, device, seed=3000 + rank,
+                                                gt_side=wl["gt_side"])
+    path = RegionProposalPath(cfg, B, C, device, train=True, depth=2)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(steps)]
+    ready = torch.cuda.Event()
+    ready.record(torch.cuda.current_stream(device))
+    for w in range(warmup):
+        path.run(fmap, score, coord, gt, label, seed=w, inputs_ready=ready)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        path.run(fmap, score, coord, gt, label, seed=100 + k, roi_events=ev[k], inputs_ready=ready)
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    roi_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    ok = verify_against_oracle(path, cfg, fmap, B // 2)
+    alg = algorithmic_bytes_roi(cfg, C, B)
+    from objectdetection_amd import ops
+    return {"metric": "images/sec (RPN anchor-match+proposal NMS+RoIPool) 768x768 ship"
+            if name == "ship768" else name,
+            "value": B * steps / elapsed, "unit": "images/s", "steps": steps, "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3,
+            "config": {"workload": wl["text"], "images_per_gpu_per_step": B,
+                       "batches_in_flight": 2},
+            "oracle_verified": ok,
+            "roofline": {"kernel": ops.roi_fwd_kernel_name(B, cfg.H, cfg.W, C, cfg.post_n, cfg.crop,
+                                                           cfg.pool),
+                         "bound": "hbm", "achieved": alg / (roi_ms * 1e-3) / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / (roi_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "avg_launch_ms": roi_ms, "algorithmic_bytes_per_launch": alg}}
+
+
 def verify_last_step(path, cfg, B, C, device, fmap, score, coord, gt, label, seed, image_base,
                      train, topk):
     """Outside the timed region: the last timed step's results (two batches in flight) must
@@ -287,6 +432,9 @@ def main():
                     help="total images per step, split over the ranks (strong scaling)")
     ap.add_argument("--channels", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the untimed extras of the default run (second workload, single-image "
+                         "latency, the step through the reference's function names)")
     ap.add_argument("--inference", action="store_true", help="skip the training-only stages")
     ap.add_argument("--depth", type=int, default=2, choices=(1, 2),
                     help="batches in flight: 2 overlaps the proposals of batch i+1 with the RoI "
@@ -387,6 +535,7 @@ def main():
         nms_busy_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_nms]))
         from objectdetection_amd import ops
         kept = path.keep_count.float().mean().item()
+        oracle_ok = verify_against_oracle(path, cfg, fmap, B // 2)
         verified = verify_last_step(path, cfg, B, C, device, fmap, score, coord, gt, label,
                                     seed=100 + args.steps - 1, image_base=rank * B,
                                     train=not args.inference, topk=args.topk)
@@ -407,19 +556,20 @@ def main():
             if not args.inference else None
         alg = algorithmic_bytes_roi(cfg, C, B)
         achieved = alg / (roi_ms * 1e-3) / 1e9
+        # counter-derived numbers are NOT measured in this run: they come from records the
+        # builder collected with rocprofv3 --pmc, quoted only if collected on these kernel sources
         traffic = bounds = lds_rates = None
-        tf = os.path.join(ROOT, "profiles", "roi_fwd_traffic.json")
-        if os.path.exists(tf):
-            with open(tf) as fh:
-                rec = json.load(fh)
+        rec, traffic_src = profile_record("roi_fwd_traffic.json")
+        if rec is not None:
             if rec.get("batch") == B and rec.get("channels") == C and args.config == rec.get("config"):
                 krec = rec.get("kernels", {}).get(roi_kernel, {})
                 traffic = krec.get("hbm_bytes_per_launch")
                 bounds = krec.get("co_bounds")
-        lf = os.path.join(ROOT, "profiles", "lds_bank_conflicts.json")
-        if os.path.exists(lf):
-            with open(lf) as fh:
-                lds_rates = json.load(fh).get("rates")
+            else:
+                traffic_src = "profiles/roi_fwd_traffic.json is for another workload: not quoted"
+        lrec, lds_src = profile_record("lds_bank_conflicts.json")
+        if lrec is not None:
+            lds_rates = lrec.get("rates")
         out = {
             "metric": "images/sec (RPN anchor-match+proposal NMS+RoIPool) "
                       + ("600x1000" if args.config == "600x1000" else "768x768 ship"),
@@ -431,6 +581,9 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "nms_us_per_image": nms_ms * 1e3 / B,
+            "nms_us_per_image_note": f"one NMS call over the {B}-image batch, alone on the chip, "
+                                     f"divided by {B} (amortised); nms_us_single_image is one "
+                                     "image's own call",
             "nms_us_per_image_clustered": nms_cl_ms * 1e3 / B,
             "nms_us_per_image_in_step": nms_busy_ms * 1e3 / B,
             "scaling": scaling,
@@ -447,7 +600,14 @@ def main():
                 "mean_kept_proposals": kept,
                 "clustered_nms_mean_kept": nms_cl_kept,
             },
-            "verified": verified,
+            "pipelining_verified": verified,
+            "pipelining_verified_note": "last timed step (two batches in flight) == plain "
+                                        "one-batch rerun on the same kernels, bit for bit",
+            "oracle_verified": oracle_ok,
+            "oracle_verified_note": f"image {B // 2} of the last timed step: keep list, proposals "
+                                    "and the whole pooled tensor == CPU oracle (C restatement), "
+                                    "bit for bit",
+            "kernel_sources_sha": sources_sha(),
             "roofline": {
                 "kernel": roi_kernel,
                 "bound": "hbm",
@@ -456,7 +616,9 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_source": traffic_src,
                 "avg_launch_ms": roi_ms,
+                "avg_launch_ms_source": "HIP events around the kernel inside the timed loop (this run)",
                 "avg_launch_ms_alone": roi_alone_ms,
                 "frac_alone": alg / (roi_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_launch": alg,
@@ -465,11 +627,26 @@ def main():
         }
         if kernels is not None:
             out["kernels"] = kernels
-        if lds_rates is not None:
-            out["lds_bank_conflict_rate"] = lds_rates
+        out["lds_bank_conflict_rate"] = lds_rates
+        out["lds_bank_conflict_rate_source"] = lds_src
+        extras = not args.no_extras and world == 1 and args.config == "600x1000" \
+            and not args.inference
+        if extras:
+            api_ms = reference_api_step(cfg, B, C, device, fmap, score, coord, gt, label,
+                                        path.anchor, args.steps, args.warmup)
+            out["reference_api"] = {
+                "ms_per_step": api_ms, "images_per_s": B / (api_ms * 1e-3),
+                "vs_path_run": api_ms / (elapsed / args.steps * 1e3),
+                "note": "the same step through the reference's function names: patch_batch (batched) "
+                        "+ making_frcnn_input(fuse_pool=True) on their kept buffer sets"}
         if not args.no_cpu_baseline and world == 1:       # the CPU leg is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(cfg, fmap, score, coord, gt, label)
             out["cpu_baseline_numpy"] = cpu_baseline_numpy(cfg, fmap, score, coord, gt, label)
+        if extras:
+            del path
+            torch.cuda.empty_cache()
+            out["single_image"] = single_image(cfg, C, device)
+            out["secondary"] = secondary_workload("ship768", C, device, args.steps, args.warmup, rank)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -83,7 +83,7 @@ def making_frcnn_input(gt_box: torch.Tensor, label: torch.Tensor, fmap: torch.Te
                        pred_reg: torch.Tensor, pred_obj: torch.Tensor,
                        anchor_box: Optional[torch.Tensor] = None, cfg: PathConfig = REFERENCE,
                        keys=None, seed: int = 0, image_base: int = 0, fuse_pool: bool = False,
-                       check: bool = True):
+                       check: bool = True, cache: bool = True, inputs_ready=None):
     """Head inputs and targets.  Counterpart of module/data.py:200-329.
 
     The reference reads `anchor_box` from an undefined global (data.py:205);

@@ -23,9 +23,29 @@ def propose(score: torch.Tensor, coord: torch.Tensor, anchor_box: torch.Tensor,
                 cand=cand)
 
 
+def _is_planar(fmap: torch.Tensor) -> bool:
+    """True for the permuted [B,H,W,C] view of a contiguous [B,C,H,W] tensor."""
+    B, H, W, C = fmap.shape
+    return C > 1 and tuple(fmap.stride()) == (C * H * W, W, 1, H * W)
+
+
+def _path_for(fmap, score, anchor_box, cfg, train, fuse_pool, inputs_ready=None):
+    """The kept buffer set for a call of these dimensions, its anchors bound to `anchor_box`."""
+    from ..pipeline import cached_path
+    B, H, W, C = fmap.shape
+    if (H, W) != (cfg.H, cfg.W) or tuple(anchor_box.shape) != (cfg.H, cfg.W, cfg.A, 4):
+        raise ValueError(f"fmap {tuple(fmap.shape)} / anchor_box {tuple(anchor_box.shape)} do not "
+                         f"match cfg ({cfg.H}x{cfg.W}x{cfg.A}): pass the PathConfig of this grid")
+    path = cached_path(cfg, B, C, fmap.device, train=train, fuse_pool=fuse_pool,
+                       fmap_planar=_is_planar(fmap))
+    path.anchor = anchor_box.to(torch.float32).contiguous()
+    return path
+
+
 def process_fmap(fmap: torch.Tensor, score: torch.Tensor, coord: torch.Tensor,
                  anchor_box: torch.Tensor, cfg: PathConfig = REFERENCE, fuse_pool: bool = False,
-                 workspace: Optional[torch.Tensor] = None):
+                 workspace: Optional[torch.Tensor] = None, cache: bool = True,
+                 inputs_ready=None):
     """Counterpart of module/model.py:43-57.
 
     fmap [B,H,W,C] (NHWC, as the reference's block5_conv3 output), score
@@ -33,11 +53,23 @@ def process_fmap(fmap: torch.Tensor, score: torch.Tensor, coord: torch.Tensor,
     proposed) with crop_fmap [B,post_n,14,14,C] like the reference, or -- with
     fuse_pool=True -- the pooled [B,post_n,7,7,C] tensor that the head's first
     layer (module/model.py:30) would make of it.
+
+    cache=True (default): the call runs on a buffer set kept per (cfg, B, C, device) --
+    radix-sort top-k, NMS and band-resident RoI kernel with their workspaces, nothing allocated
+    per call.  The returned tensors belong to that set: `crop_fmap` is overwritten by the next
+    call with the same dimensions, `proposed` by the one after it; clone what must live longer
+    (pipeline.clear_path_cache() frees the sets).  `inputs_ready`: an event after which the inputs
+    may be read -- with it the proposals of this call are computed beside the RoI kernel of the
+    call before.  cache=False allocates every output per call, as TensorFlow does.
     """
-    pr = propose(score, coord, anchor_box, cfg, workspace)
-    pool = cfg.pool if fuse_pool else 1
-    crop_fmap, _ = ops.roi_crop_pool_fwd(fmap, pr["proposed"], cfg.crop, pool)
-    return crop_fmap, pr["proposed"]
+    if not cache or workspace is not None:
+        pr = propose(score, coord, anchor_box, cfg, workspace)
+        pool = cfg.pool if fuse_pool else 1
+        crop_fmap, _ = ops.roi_crop_pool_fwd(fmap, pr["proposed"], cfg.crop, pool)
+        return crop_fmap, pr["proposed"]
+    path = _path_for(fmap, score, anchor_box, cfg, False, fuse_pool)
+    path.run(fmap, score.contiguous(), coord.contiguous(), inputs_ready=inputs_ready)
+    return path.pooled, path.proposed
 
 
 def roi_pool(fmap: torch.Tensor, proposed: torch.Tensor, cfg: PathConfig = REFERENCE,

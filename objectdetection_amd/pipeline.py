@@ -45,7 +45,7 @@ class RegionProposalPath:
     def __init__(self, cfg: PathConfig = REFERENCE, batch: int = 1, channels: int = 512,
                  device="cuda", train: bool = True, want_winner: bool = False,
                  fuse_pool: bool = True, depth: int = 1, topk: str = "sort",
-                 alloc_pooled: bool = True, fmap_planar: bool = False):
+                 alloc_pooled: bool = True, fmap_planar: bool = False, rpn_targets: bool = True):
         if depth not in (1, 2):
             raise ValueError("depth must be 1 or 2")
         if topk not in ("sort", "lds"):
@@ -54,6 +54,9 @@ class RegionProposalPath:
         self.cfg, self.B, self.C = cfg, batch, channels
         self.device = torch.device(device)
         self.train, self.fuse_pool, self.depth = train, fuse_pool, depth
+        # rpn_targets=False: train without stages 1-2 (making_frcnn_input's share of the targets;
+        # the reference computes the RPN mini-batch elsewhere, in patch_batch)
+        self.rpn_targets = bool(train and rpn_targets)
         self.side = torch.cuda.Stream(self.device) if train else None
         self.prop_stream = torch.cuda.Stream(self.device) if depth == 2 else None
         # the RoI geometry (frcnn_roi_fwd_prepare) is computed on the proposal stream right behind
@@ -86,14 +89,16 @@ class RegionProposalPath:
                      proposed=e((B, R, 4), f32), keep_pos=e((B, R), i32), keep_count=e((B,), i32),
                      roi_ws=e((roi_ws_bytes,), u8),
                      ev=[torch.cuda.Event() for _ in range(5)])
-            if train:
-                S, S2 = cfg.rpn_batch, cfg.head_batch
+            if self.rpn_targets:
+                S = cfg.rpn_batch
                 d.update(max_iou=e((B, N), f32), best_gt=e((B, N), i32), flags=e((B, N), u8),
                          rpn=dict(label=e((B, S), f32), anchor=e((B, S, 4), f32),
                                   gt=e((B, S, 4), f32), gt_list=e((B, S), i64),
                                   pos=e((B, S, 3), i64), reg=e((B, S, 4), f32),
-                                  counts=e((B, 4), i32)),
-                         p_label=e((B, R), i64), gt_mask=e((B, R), i32),
+                                  counts=e((B, 4), i32)))
+            if train:
+                S2 = cfg.head_batch
+                d.update(p_label=e((B, R), i64), gt_mask=e((B, R), i32),
                          gt_onehot=e((B, R, cfg.num_classes), f32), gt_coord=e((B, R, 4), f32),
                          p_best=e((B, R), i32), p_iou=e((B, R), f32),
                          tindex=e((B, S2), i64), head_counts=e((B, 4), i32))
@@ -209,11 +214,12 @@ class RegionProposalPath:
         ev[1].record(prop)                             # proposals ready
         # (the host queues the proposal chain first: with small images it is the longer one)
         if self.train:
-            G = gt.shape[1]
-            ss = self.side.cuda_stream
             self.side.wait_event(ready)
             if self.depth == 2 and self._calls > self.depth:
                 self.side.wait_event(ev[4])
+        if self.rpn_targets:
+            G = gt.shape[1]
+            ss = self.side.cuda_stream
             check("frcnn_iou_assign", lib.frcnn_iou_assign(
                 _p(self.anchor), N, _p(gt), B, G, cfg.rpn_pos_thr, cfg.rpn_neg_thr,
                 _p(d["max_iou"]), _p(d["best_gt"]), _p(d["flags"]), None, ss))
@@ -264,3 +270,37 @@ class RegionProposalPath:
             main.wait_event(ev[2])                     # join: everything is ordered on `main` again
         ev[4].record(main)                             # this set may be rewritten after here
         return self
+
+
+# ---- buffer sets for the reference-named functions ---------------------------------------------
+# process_fmap / making_frcnn_input (module/model.py, module/data.py) are plain functions in the
+# reference; here they run on a RegionProposalPath that is built on first use for a
+# (configuration, batch, channels, device, mode) and kept, so that a caller of the reference's
+# names gets the workspace-backed kernels (band-resident RoI forward, radix-sort top-k) and no
+# per-call allocation.  A few paths are kept (least recently used goes first): a path at the
+# benchmark size holds a 12.8 GB pooled tensor.
+_PATH_CACHE: "dict" = {}
+_PATH_CACHE_MAX = 4
+
+
+def cached_path(cfg: PathConfig, batch: int, channels: int, device, *, train: bool,
+                fuse_pool: bool, want_winner: bool = False, fmap_planar: bool = False,
+                depth: int = 2) -> RegionProposalPath:
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device(device.type, torch.cuda.current_device())
+    key = (cfg, batch, channels, device, train, fuse_pool, want_winner, fmap_planar, depth)
+    path = _PATH_CACHE.pop(key, None)
+    if path is None:
+        while len(_PATH_CACHE) >= _PATH_CACHE_MAX:
+            _PATH_CACHE.pop(next(iter(_PATH_CACHE)))
+        path = RegionProposalPath(cfg, batch, channels, device, train=train,
+                                  want_winner=want_winner, fuse_pool=fuse_pool, depth=depth,
+                                  fmap_planar=fmap_planar, rpn_targets=False)
+    _PATH_CACHE[key] = path                      # most recently used last
+    return path
+
+
+def clear_path_cache() -> None:
+    """Drops the buffer sets process_fmap / making_frcnn_input keep between calls."""
+    _PATH_CACHE.clear()
