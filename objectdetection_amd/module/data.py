@@ -97,11 +97,31 @@ def making_frcnn_input(gt_box: torch.Tensor, label: torch.Tensor, fmap: torch.Te
     B == 2 (data.py:266-298); its else branch (data.py:300-316), taken for any other B, draws
     one joint list over the whole [B,R] tensor, caps the positives at 32 in total and returns
     [1,128].  For B == 1 the two agree; the joint branch for B >= 3 is not reproduced.
+
+    cache=True (default) with counter keys (keys=None): the call runs on a buffer set kept per
+    (cfg, B, C, device), see process_fmap -- crop_fmap is overwritten by the next call of the same
+    dimensions, proposed / tindex by the one after it; the three gathered targets are new
+    tensors.  Injected keys (parity runs) and cache=False take the allocate-per-call route.
     """
     if anchor_box is None:
         raise ValueError("anchor_box is required (the reference reads an undefined global here)")
+    B = fmap.shape[0]
+    if cache and keys is None:
+        path = _model._path_for(fmap, pred_obj, anchor_box, cfg, True, fuse_pool)
+        path.run(fmap, pred_obj.contiguous(), pred_reg.contiguous(),
+                 gt_box.reshape(B, -1, 4).contiguous(),
+                 label.reshape(B, -1).to(torch.int64).contiguous(), seed=seed,
+                 image_base=image_base, inputs_ready=inputs_ready)
+        if check:
+            _check_counts(path.head_counts, "making_frcnn_input")
+        tindex = path.tindex
+        gt_label2 = torch.gather(path.gt_onehot, 1,
+                                 tindex.unsqueeze(-1).expand(-1, -1, cfg.num_classes))
+        gt_coord2 = torch.gather(path.gt_coord, 1, tindex.unsqueeze(-1).expand(-1, -1, 4))
+        gt_mask2 = torch.gather(path.gt_mask, 1, tindex)
+        return path.pooled, gt_label2, gt_mask2, gt_coord2, path.proposed, tindex
     crop_fmap, proposed = _model.process_fmap(fmap, pred_obj, pred_reg, anchor_box, cfg,
-                                              fuse_pool=fuse_pool)
+                                              fuse_pool=fuse_pool, cache=False)
     lab = ops.label_proposals(proposed, gt_box.reshape(fmap.shape[0], -1, 4),
                               label.reshape(fmap.shape[0], -1).to(torch.int64), cfg.fg_thr,
                               cfg.iou_floor, cfg.bg_label, cfg.num_classes)
