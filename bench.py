@@ -169,14 +169,18 @@ def single_image(cfg, C, device, seed=4242):
     a = path.anchor.reshape(-1, 4)
     topk_ms = timed_alone(lambda: ops.topk(score.reshape(1, -1), cfg.pre_k, a, coord, "sort",
                                            workspace=path.topk_ws), device, reps=40, skip=10)
-    nms_ms = timed_alone(lambda: ops.nms(path.cand, cfg.nms_thr, cfg.post_n, workspace=path.nms_ws),
+    nms_call = ops.nms_fused if path.nms == "fused" else ops.nms
+    nms_ms = timed_alone(lambda: nms_call(path.cand, cfg.nms_thr, cfg.post_n, workspace=path.nms_ws),
                          device, reps=40, skip=10)
+    chunked_ms = timed_alone(lambda: ops.nms(path.cand, cfg.nms_thr, cfg.post_n), device, reps=40,
+                             skip=10)
     roi_ms = timed_alone(lambda: ops.roi_crop_pool_fwd(fmap, path.proposed, cfg.crop, cfg.pool,
                                                        out=path.pooled, workspace=path.roi_ws),
                          device, reps=40, skip=10)
     return dict(latency_b1_ms=min(plain, replay), latency_b1_plain_launches_ms=plain,
                 latency_b1_graph_replay_ms=replay, topk_us_single_image=topk_ms * 1e3,
-                nms_us_single_image=nms_ms * 1e3, roi_us_single_image=roi_ms * 1e3,
+                nms_us_single_image=nms_ms * 1e3, nms_route_single_image=path.nms,
+                nms_us_single_image_chunked=chunked_ms * 1e3, roi_us_single_image=roi_ms * 1e3,
                 kept=int(path.keep_count[0]),
                 note="one 600x1000 image, inference stages (top-k, NMS, RoI crop + pool), idle chip")
 

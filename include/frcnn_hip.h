@@ -172,6 +172,21 @@ int frcnn_nms(const float* boxes, int B, int K, float iou_threshold, int post_n,
               float* proposed, int32_t* keep_pos, int32_t* keep_count,
               void* workspace, size_t workspace_bytes, frcnn_stream_t stream);
 
+/* The same NMS in ONE kernel launch (plus two tiny launches that clear its counters), for a few
+ * images at a time (B <= 8): the reference's own inference call runs one image
+ * (Faster_RCNN/model_train.py:741-743), where the chunked form above is a chain of 24 dependent
+ * launches.  A persistent grid: one 1,024-thread workgroup per image resolves a chunk of 1,024
+ * candidates by relaxation over all its columns at once, the other workgroups compute the mask
+ * tiles of the following chunk beside it; hand-off through counters in the workspace.  Same
+ * arguments and bit-identical results; workspace frcnn_nms_fused_workspace_bytes(B,K,post_n)
+ * bytes (about 0.5 MB per image), 256-byte aligned, contents on entry do not matter.  The grid's
+ * waits are bounded: should it ever fail to become resident as a whole (it is at most 256
+ * workgroups), it drains after about a second and keep_count[b] = -1 tells. */
+size_t frcnn_nms_fused_workspace_bytes(int B, int K, int post_n);
+int frcnn_nms_fused(const float* boxes, int B, int K, float iou_threshold, int post_n,
+                    float* proposed, int32_t* keep_pos, int32_t* keep_count,
+                    void* workspace, size_t workspace_bytes, frcnn_stream_t stream);
+
 /* The same NMS for callers that cannot allocate device memory (code under HIP graph capture,
  * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.
  * Same arguments, results and kernels as frcnn_nms, minus the workspace: the masks, the kept

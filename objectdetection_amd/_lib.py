@@ -55,6 +55,8 @@ _SIGS = {
     "frcnn_nms_workspace_bytes": (_sz, [_i, _i, _i]),
     "frcnn_nms": (_i, [_p, _i, _i, _f, _i, _p, _p, _p, _p, _sz, _p]),
     "frcnn_nms_static": (_i, [_p, _i, _i, _f, _i, _p, _p, _p, _p]),
+    "frcnn_nms_fused_workspace_bytes": (_sz, [_i, _i, _i]),
+    "frcnn_nms_fused": (_i, [_p, _i, _i, _f, _i, _p, _p, _p, _p, _sz, _p]),
     "frcnn_roi_crop_pool_fwd": (_i, [_p, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _p, _i, _i, _i,
                                      _i, _p, _p, _p]),
     "frcnn_roi_fwd_workspace_bytes": (_sz, [_i, _i]),

@@ -412,6 +412,390 @@ nms_scan_kernel(const float4* __restrict__ boxes, unsigned long long* __restrict
     }
 }
 
+
+// =========================================================================
+// NMS in ONE launch, for a few images (latency)
+// =========================================================================
+// The chunked formulation above costs two dependent launches per 1,024 candidates and a serial
+// walk of 16 column blocks per chunk: for one image that chain is the whole cost (24 launches,
+// ~190 blocks at > 1 us each).  Here one persistent grid does it all:
+//   * workgroups 0 .. B-1 are RESOLVERS, one per image: thread = one column of the current chunk
+//     (wave = column block).  A column's suppressors inside the chunk (maskT: in-chunk triangle)
+//     and in the chunk before (maskR: a full 16 x 16 rectangle of tiles) are mask words that
+//     depend on the boxes only; columns the boxes kept in still earlier chunks suppress arrive as
+//     one word per column block (deadK).  The chunk is then resolved by relaxation over all 1,024
+//     columns at once: a column whose suppressors are all gone is kept, one with a kept
+//     suppressor is gone -- both are final facts, so stale reads of other waves' words only delay
+//     a decision, and the fixed point is the greedy result (at most 16 rounds: a column block is
+//     final once the blocks before it are).
+//   * the other workgroups are WORKERS: stage s = every tile that chunk s needs (triangle,
+//     rectangle against chunk s-1, kept tiles against what was kept up to chunk s-2), written
+//     into buffers of parity s & 1.  Stage s may start once chunk s-2 is resolved, so it runs
+//     BESIDE the resolution of chunk s-1: the resolver's chain is relaxation after relaxation,
+//     the tiles arrive off its critical path.
+// Hand-off is by counters in the workspace (agent-scope release / acquire: each XCD has its own
+// L2).  Work is assigned statically to worker waves, so progress needs every workgroup of the
+// grid to become resident: the grid is at most 256 workgroups (one per compute unit), none of
+// them waits for anything but the counters, and the resolvers are dispatched first.
+constexpr int NF_THREADS = 1024;
+constexpr int NF_WAVES = NF_THREADS / 64;
+static_assert(NF_WAVES == NMS_CW, "the resolver gives every column block of a chunk one wave");
+constexpr int NF_MAX_B = 8;
+constexpr int NF_DONE = 0x7FFFFFFF;
+constexpr int NF_RECT = NMS_CW * NMS_CW;
+
+struct NfImage { int scan_done; int abort; int pad[2]; };   // chunks resolved (NF_DONE: finished)
+
+struct NfWorkspace {
+    NfImage* img;                   // [B]
+    int* stage_done;                // [B][nchunk] worker workgroups that finished stage s
+    int* count_after;               // [B][nchunk] boxes kept after chunk c
+    unsigned long long* deadK;      // [B][2][NMS_CW]
+    unsigned long long* maskT;      // [B][2][NMS_CW][NMS_COLS]
+    unsigned long long* maskR;      // [B][2][NMS_CW][NMS_COLS]
+    unsigned long long* sumT;       // [B][2][NMS_CW][NMS_CW] bit l: column l of the tile has a non-zero word
+    unsigned long long* sumR;       // [B][2][NMS_CW][NMS_CW]
+    int32_t* keep_idx;              // [B][post_n]
+    unsigned long long* trace;      // timing experiments only (FRCNN_NF_TRACE builds)
+};
+
+#ifdef FRCNN_NF_TRACE
+#define NF_TRACE(slot, extra)                                                                   \
+    do { if (tid == 0) ws.trace[(slot)] = (__builtin_amdgcn_s_memrealtime() << 8) | (unsigned long long)(extra); } while (0)
+#else
+#define NF_TRACE(slot, extra) do { } while (0)
+#endif
+
+// Everything one XCD writes for another to read inside this launch goes through agent-scope
+// atomic loads and stores (they are served at the coherent point, past the per-XCD L2s), ordered
+// by "all my stores have completed" (vmcnt) before the counter that announces them.  Release /
+// acquire fences would do the same by writing back and invalidating the whole L2 of an XCD: with
+// hundreds of workgroups fencing per stage, no load of anyone hit a cache any more.
+__device__ __forceinline__ int nf_load(const int* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void nf_store(int* p, int v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long nf_load64(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void nf_store64(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void nf_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Polls *p until it reaches `want`.  Every wait in the grid is bounded: after about a second
+// without progress (a grid that cannot become resident as a whole) the waiter raises the abort
+// word of image 0, which every other wait also watches, and the grid drains; the call then
+// reports keep_count = -1.  Returns the value seen, or -1 on abort.
+constexpr int NF_SPINS = 1 << 21;            // x ~0.5 us
+__device__ __forceinline__ int nf_wait(const int* p, int want, int* abort_word) {
+    for (int i = 0; i < NF_SPINS; ++i) {
+        const int v = nf_load(p);
+        if (v >= want) return v;
+        if ((i & 63) == 63 && nf_load(abort_word) != 0) return -1;
+        __builtin_amdgcn_s_sleep(16);               // ~0.5 us: hundreds of waiters poll one word
+    }
+    __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return -1;
+}
+
+__global__ void nms_fused_init_kernel(int* words, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) words[i] = 0;
+}
+
+// tile t = (row block ibl of chunk s-1, column block jbl of chunk s): a full 64 x 64 tile
+__device__ __forceinline__ void nms_rect_tile(const float4* __restrict__ bx, int K, int cb0, int t,
+                                              NBox* s_col, float thr, float c1, float thr_lo,
+                                              unsigned long long* __restrict__ mr,
+                                              unsigned long long* __restrict__ sum, int lane) {
+    const int ibl = t / NMS_CW, jbl = t - ibl * NMS_CW;
+    if ((cb0 + jbl) * 64 >= K) return;                  // wave-uniform
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int j = (cb0 + jbl) * 64 + lane;
+    s_col[lane] = norm_box(j < K ? bx[j] : zero4, thr_lo);
+    __builtin_amdgcn_wave_barrier();
+    const int i = (cb0 - NMS_CW + ibl) * 64 + lane;     // always < K: the chunk before is complete
+    const NBox a = norm_box(bx[i], thr_lo);
+    const float c1l = a.area < NMS_TINY_AREA ? __builtin_inff() : c1;
+    const unsigned long long mine = mask_tile<false>(a, c1l, s_col, thr, lane);
+    // most columns have no suppressor in a given row block: only non-zero words are stored, and
+    // a word per tile says which (the resolver fetches nothing else)
+    const unsigned long long nz = __ballot(mine != 0ull);
+    if (mine != 0ull) nf_store64(&mr[(size_t)ibl * NMS_COLS + jbl * 64 + lane], mine);
+    if (lane == 0) nf_store64(&sum[ibl * NMS_CW + jbl], nz);
+    __builtin_amdgcn_wave_barrier();                    // the next tile of this wave rewrites s_col
+}
+
+// nms_tri_tile for the one-launch kernel: the same tile, stored sparsely as above
+__device__ __forceinline__ void nms_tri_tile_sparse(const float4* __restrict__ bx, int K, int cb0, int t,
+                                                    NBox* s_col, float thr, float c1, float thr_lo,
+                                                    unsigned long long* __restrict__ md,
+                                                    unsigned long long* __restrict__ sum, int lane) {
+    const int p = t / (NMS_CW + 1), q = t - p * (NMS_CW + 1);
+    int jbl, ibl;
+    if (q <= p) { jbl = p; ibl = q; }
+    else { jbl = NMS_CW - 1 - p; ibl = q - p - 1; }
+    if ((cb0 + jbl) * 64 >= K) return;                  // wave-uniform
+    const int j = (cb0 + jbl) * 64 + lane;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    s_col[lane] = norm_box(j < K ? bx[j] : zero4, thr_lo);
+    __builtin_amdgcn_wave_barrier();
+    const int i = (cb0 + ibl) * 64 + lane;
+    const NBox a = norm_box(i < K ? bx[i] : zero4, thr_lo);
+    const float c1l = a.area < NMS_TINY_AREA ? __builtin_inff() : c1;
+    const unsigned long long mine = ibl == jbl ? mask_tile<true>(a, c1l, s_col, thr, lane)
+                                               : mask_tile<false>(a, c1l, s_col, thr, lane);
+    const unsigned long long nz = __ballot(mine != 0ull);
+    if (mine != 0ull) nf_store64(&md[(size_t)ibl * NMS_COLS + jbl * 64 + lane], mine);
+    if (lane == 0) nf_store64(&sum[ibl * NMS_CW + jbl], nz);
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ void __launch_bounds__(NF_THREADS)
+nms_fused_kernel(const float4* __restrict__ boxes, int B, int K, int post_n, int nchunk, int NW,
+                 float thr, float c1, float thr_lo, NfWorkspace ws,
+                 float4* __restrict__ proposed, int32_t* __restrict__ keep_pos,
+                 int32_t* __restrict__ keep_count) {
+    __shared__ NBox s_col[NF_WAVES][64];
+    __shared__ unsigned long long kept_w[NMS_CW], gone_w[NMS_CW], prevk[NMS_CW];
+    __shared__ int und_w[2][NMS_CW];
+    __shared__ int s_flag;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if ((int)blockIdx.x >= B) {
+        // ------------------------------------------------------------------ worker
+        // jobs are dealt to the workgroups first and to the waves of a workgroup second: a stage
+        // has fewer tiles than the grid has waves, and sixteen busy waves on one compute unit
+        // run at a quarter of the speed of four on each of four
+        const int TW = NW * NF_WAVES;
+        const int gw0 = wave * NW + ((int)blockIdx.x - B);
+        for (int s = 0; s < nchunk; ++s) {
+            const int cb0 = s * NMS_CW;
+            for (int b = 0; b < B; ++b) {
+                NfImage* im = ws.img + b;
+                // stage s rewrites the buffers chunk s-2 was resolved from and needs what was
+                // kept up to chunk s-2
+                if ((int)blockIdx.x == B && b == 0) NF_TRACE(1024 + s * 4 + 0, 0);
+                if (tid == 0) s_flag = nf_wait(&im->scan_done, s - 1, &ws.img[0].abort);
+                __syncthreads();
+                if ((int)blockIdx.x == B && b == 0) NF_TRACE(1024 + s * 4 + 1, 0);
+                const int sd = s_flag;
+                __syncthreads();                        // s_flag is rewritten for the next image
+                if (sd < 0) return;                     // workgroup-uniform: the grid is draining
+                if (sd == NF_DONE) continue;            // workgroup-uniform: the image is finished
+#ifdef FRCNN_NF_TRACE
+                if ((int)blockIdx.x == B && b == 0) NF_TRACE(1536 + s * 4 + 0, 0);
+#endif
+                const float4* bx = boxes + (size_t)b * K;
+                const int par = s & 1;
+                unsigned long long* dk = ws.deadK + ((size_t)b * 2 + par) * NMS_CW;
+                unsigned long long* mt = ws.maskT + ((size_t)b * 2 + par) * NMS_CW * NMS_COLS;
+                unsigned long long* mr = ws.maskR + ((size_t)b * 2 + par) * NMS_CW * NMS_COLS;
+                unsigned long long* st_ = ws.sumT + ((size_t)b * 2 + par) * NMS_CW * NMS_CW;
+                unsigned long long* sr_ = ws.sumR + ((size_t)b * 2 + par) * NMS_CW * NMS_CW;
+                const int count = s >= 2 ? nf_load(&ws.count_after[(size_t)b * nchunk + s - 2]) : 0;
+                const int nkt = (count + 63) >> 6;
+                const int nkept = nkt * NMS_CW, nrect = s >= 1 ? NF_RECT : 0;
+                const int njobs = nkept + nrect + NMS_TRI;
+                const int* kidx = ws.keep_idx + (size_t)b * post_n;
+                const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                int gw = gw0 + b * 131;
+                gw -= (gw / TW) * TW;
+#pragma unroll 1
+                for (int j = gw; j < njobs; j += TW) {                 // wave-uniform
+                    if (j < nkept) {
+                        const int kt = j / NMS_CW, jbl = j - kt * NMS_CW;
+                        const int jb = cb0 + jbl;
+                        if (jb * 64 >= K) continue;
+                        const int col = jb * 64 + lane;
+                        float4 cbx = bx[col < K ? col : K - 1];
+                        if (col >= K) cbx = zero4;
+                        s_col[wave][lane] = norm_box(cbx, thr_lo);
+                        __builtin_amdgcn_wave_barrier();
+                        const int slot = kt * 64 + lane;
+                        float4 rbx = bx[slot < count ? nf_load(&kidx[slot]) : 0];
+                        if (slot >= count) rbx = zero4;
+                        const NBox a = norm_box(rbx, thr_lo);
+                        const float c1l = a.area < NMS_TINY_AREA ? __builtin_inff() : c1;
+                        const unsigned long long dead = mask_tile_any(a, c1l, s_col[wave], thr);
+                        if (lane == 0 && dead != 0ull)
+                            __hip_atomic_fetch_or(&dk[jbl], dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __builtin_amdgcn_wave_barrier();
+                    } else if (j < nkept + nrect) {
+                        nms_rect_tile(bx, K, cb0, j - nkept, s_col[wave], thr, c1, thr_lo, mr, sr_, lane);
+                    } else {
+#ifdef FRCNN_NF_TRACE
+                        {
+                            const float4 probe = bx[(cb0 * 64 + lane) < K ? cb0 * 64 + lane : 0];
+                            asm volatile("s_waitcnt vmcnt(0)" :: "v"(probe.x));
+                            if ((int)blockIdx.x == B && b == 0) NF_TRACE(1536 + s * 4 + 1, 0);
+                        }
+#endif
+                        nms_tri_tile_sparse(bx, K, cb0, j - nkept - nrect, s_col[wave], thr, c1, thr_lo, mt,
+                                            st_, lane);
+#ifdef FRCNN_NF_TRACE
+                        asm volatile("s_waitcnt vmcnt(0)");
+                        if ((int)blockIdx.x == B && b == 0) NF_TRACE(1536 + s * 4 + 2, 0);
+#endif
+                    }
+                }
+                nf_stores_done();
+                __syncthreads();                        // every wave's stores have completed
+                if ((int)blockIdx.x == B && b == 0) NF_TRACE(1024 + s * 4 + 2, njobs);
+                if (tid == 0) {
+                    __hip_atomic_fetch_add(&ws.stage_done[(size_t)b * nchunk + s], 1, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if ((int)blockIdx.x == B && b == 0) NF_TRACE(1024 + s * 4 + 3, 0);
+            }
+        }
+        return;
+    }
+    // ---------------------------------------------------------------------- resolver
+    const int b = blockIdx.x;
+    const float4* bx = boxes + (size_t)b * K;
+    float4* prop = proposed + (size_t)b * post_n;
+    int* kidx = ws.keep_idx + (size_t)b * post_n;
+    int32_t* kp = keep_pos ? keep_pos + (size_t)b * post_n : nullptr;
+    NfImage* im = ws.img + b;
+    __builtin_amdgcn_s_setprio(3);
+    int count = 0;
+    if (tid < NMS_CW) prevk[tid] = 0ull;
+#ifdef FRCNN_NF_TRACE
+    if (tid == 0 && b == 0) { ws.trace[2040] = __builtin_amdgcn_s_memrealtime(); ws.trace[2041] = __builtin_amdgcn_s_memtime(); }
+#endif
+#pragma unroll 1
+    for (int c = 0; c < nchunk; ++c) {
+        if (b == 0) NF_TRACE(c * 8 + 0, 0);
+        if (tid == 0) s_flag = nf_wait(&ws.stage_done[(size_t)b * nchunk + c], NW, &ws.img[0].abort);
+        __syncthreads();
+        if (b == 0) NF_TRACE(c * 8 + 1, 0);
+        if (s_flag < 0) {                               // workgroup-uniform: give up, tell the caller
+            if (tid == 0) {
+                if (keep_count) keep_count[b] = -1;
+                nf_store(&im->scan_done, NF_DONE);
+            }
+            return;
+        }
+        const int par = c & 1;
+        const int cb0 = c * NMS_CW;
+        const int colb = wave * 64 + lane;              // column inside the chunk
+        const int col = cb0 * 64 + colb;
+        const bool valid = col < K;
+        const unsigned long long* mt = ws.maskT + ((size_t)b * 2 + par) * NMS_CW * NMS_COLS;
+        const unsigned long long* mr = ws.maskR + ((size_t)b * 2 + par) * NMS_CW * NMS_COLS;
+        unsigned long long* dkp = ws.deadK + ((size_t)b * 2 + par) * NMS_CW;
+        // suppressor words: rows of earlier blocks of this chunk (T), of this block (diag), of the
+        // chunk before (R).  Words of nonexistent columns are never written and never used.
+        const unsigned long long* st_ = ws.sumT + ((size_t)b * 2 + par) * NMS_CW * NMS_CW;
+        const unsigned long long* sr_ = ws.sumR + ((size_t)b * 2 + par) * NMS_CW * NMS_CW;
+        // lane i < 16: the summary words of (row block i, this column block)
+        const bool blk = (cb0 + wave) * 64 < K;         // wave-uniform: the column block exists
+        const unsigned long long sT = (lane <= wave && blk) ? nf_load64(&st_[lane * NMS_CW + wave]) : 0ull;
+        const unsigned long long sR = (lane < NMS_CW && c >= 1 && blk) ? nf_load64(&sr_[lane * NMS_CW + wave]) : 0ull;
+        unsigned long long T[NMS_CW], R[NMS_CW];
+        unsigned long long diag = 0ull;
+#pragma unroll
+        for (int i = 0; i < NMS_CW; ++i) {
+            const unsigned long long nzT = uniform64(__shfl(sT, i)), nzR = uniform64(__shfl(sR, i));
+            T[i] = 0ull; R[i] = 0ull;
+            if (i < wave) { if ((nzT >> lane) & 1ull) T[i] = nf_load64(&mt[(size_t)i * NMS_COLS + colb]); }
+            else if (i == wave) { if ((nzT >> lane) & 1ull) diag = nf_load64(&mt[(size_t)i * NMS_COLS + colb]); }
+            if ((nzR >> lane) & 1ull) R[i] = nf_load64(&mr[(size_t)i * NMS_COLS + colb]);
+        }
+        const unsigned long long dk = c >= 2 ? uniform64(nf_load64(&dkp[wave])) : 0ull;
+        const float4 box = bx[valid ? col : K - 1];
+        bool gone0 = !valid || ((dk >> lane) & 1ull);
+        {
+            unsigned long long h = 0ull;
+#pragma unroll
+            for (int i = 0; i < NMS_CW; ++i) h |= R[i] & prevk[i];
+            gone0 = gone0 || h != 0ull;
+        }
+        unsigned long long my_gone = __ballot(gone0), my_kept = 0ull;
+        if (b == 0) NF_TRACE(c * 8 + 2, 0);
+        if (lane == 0) {
+            gone_w[wave] = my_gone;
+            kept_w[wave] = 0ull;
+            nf_store64(&dkp[wave], 0ull);               // handed back as zeros for stage c + 2
+        }
+        __syncthreads();
+        const unsigned long long me = 1ull << lane;
+#pragma unroll 1
+        for (int r = 0;; ++r) {
+            unsigned long long hit = 0ull, alive = 0ull;
+            const bool open = ~(my_kept | my_gone) != 0ull;         // wave-uniform
+            if (open) {
+#pragma unroll
+                for (int i = 0; i < NMS_CW; ++i) {
+                    if (i < wave) {                     // wave-uniform
+                        const unsigned long long kw = kept_w[i], gw_ = gone_w[i];
+                        hit |= T[i] & kw;
+                        alive |= T[i] & ~gw_;
+                    }
+                }
+            }
+            // this block's own triangle to a local fixed point with what is known of the others
+            while (open) {
+                const bool und = ((my_gone | my_kept) & me) == 0ull;
+                const unsigned long long k2 = __ballot(und && alive == 0ull && (diag & ~my_gone) == 0ull);
+                const unsigned long long g2 = __ballot(und && (hit != 0ull || (diag & my_kept) != 0ull));
+                if ((k2 | g2) == 0ull) break;           // wave-uniform
+                my_kept |= k2;
+                my_gone |= g2;
+            }
+            if (lane == 0) {
+                kept_w[wave] = my_kept;
+                gone_w[wave] = my_gone;
+                und_w[r & 1][wave] = ~(my_kept | my_gone) != 0ull ? 1 : 0;
+            }
+            __syncthreads();
+            const int u = lane < NMS_CW ? und_w[r & 1][lane] : 0;
+            if (__ballot(u != 0) == 0ull) { if (b == 0) NF_TRACE(c * 8 + 3, r + 1); break; }   // uniform
+        }
+        // kept columns in order, as far as there is room
+        int before = 0, total = 0;
+#pragma unroll
+        for (int i = 0; i < NMS_CW; ++i) {
+            const int n = __popcll(kept_w[i]);
+            if (i < wave) before += n;
+            total += n;
+        }
+        const int slot = count + before + __popcll(my_kept & lanemask_lt());
+        const bool keep = (my_kept & me) != 0ull && slot < post_n;
+        const unsigned long long capped = __ballot(keep);
+        if (keep) {
+            float4 v = box;
+            v.x = clip01(v.x); v.y = clip01(v.y); v.z = clip01(v.z); v.w = clip01(v.w);
+            prop[slot] = v;
+            nf_store(&kidx[slot], col);
+            if (kp) kp[slot] = col;
+        }
+        __syncthreads();                                // every wave has read kept_w / prevk
+        if (lane == 0) prevk[wave] = capped;
+        const int newcount = min(count + total, post_n);
+        const bool finished = newcount >= post_n || c == nchunk - 1;
+        if (finished) {
+            for (int sl = newcount + tid; sl < post_n; sl += NF_THREADS) {
+                prop[sl] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (kp) kp[sl] = -1;
+            }
+            if (tid == 0 && keep_count) keep_count[b] = newcount;
+        }
+        if (tid == 0) nf_store(&ws.count_after[(size_t)b * nchunk + c], newcount);
+        nf_stores_done();
+        __syncthreads();                                // all stores of this chunk have completed
+        if (tid == 0) nf_store(&im->scan_done, finished ? NF_DONE : c + 1);
+        if (b == 0) NF_TRACE(c * 8 + 4, newcount);
+#ifdef FRCNN_NF_TRACE
+        if (tid == 0 && b == 0) { ws.trace[2042] = __builtin_amdgcn_s_memrealtime(); ws.trace[2043] = __builtin_amdgcn_s_memtime(); }
+#endif
+        count = newcount;
+        if (finished) break;
+    }
+}
+
 }  // namespace frcnn
 
 using namespace frcnn;
@@ -503,6 +887,72 @@ extern "C" int frcnn_nms(const float* boxes, int B, int K, float iou_threshold, 
     if ((reinterpret_cast<uintptr_t>(workspace) & 7u) != 0) return FRCNN_E_BADARG;
     return nms_launch(boxes, B, K, iou_threshold, post_n, proposed, keep_pos, keep_count,
                       reinterpret_cast<char*>(workspace), (hipStream_t)stream);
+}
+
+
+// ---- the one-launch variant for a few images --------------------------------------------------
+static int nf_nchunk(int K) { return ((K + 63) / 64 + NMS_CW - 1) / NMS_CW; }
+static size_t nf_ints(int B, int K) { return (size_t)B * (4 + 2 * (size_t)nf_nchunk(K)); }
+
+extern "C" size_t frcnn_nms_fused_workspace_bytes(int B, int K, int post_n) {
+    if (B <= 0 || K <= 0 || post_n <= 0) return 0;
+    size_t n = align256(nf_ints(B, K) * 4) + align256((size_t)B * 2 * NMS_CW * 8) +
+               2 * align256((size_t)B * 2 * NMS_CW * NMS_COLS * 8) +
+               2 * align256((size_t)B * 2 * NMS_CW * NMS_CW * 8) + align256((size_t)B * post_n * 4);
+#ifdef FRCNN_NF_TRACE
+    n += 16384;                                 // 2,048 time stamps behind the kept index list
+#endif
+    return n;
+}
+
+extern "C" int frcnn_nms_fused(const float* boxes, int B, int K, float iou_threshold, int post_n,
+                               float* proposed, int32_t* keep_pos, int32_t* keep_count,
+                               void* workspace, size_t workspace_bytes, frcnn_stream_t stream) {
+    if (!boxes || !proposed || B <= 0 || K <= 0 || post_n <= 0) return FRCNN_E_BADARG;
+    if (!(iou_threshold >= 0.0f)) return FRCNN_E_BADARG;
+    if (B > NF_MAX_B) return FRCNN_E_UNSUPPORTED;
+    if (!workspace || workspace_bytes < frcnn_nms_fused_workspace_bytes(B, K, post_n))
+        return FRCNN_E_WORKSPACE;
+    if ((reinterpret_cast<uintptr_t>(workspace) & 255u) != 0) return FRCNN_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int nchunk = nf_nchunk(K);
+    char* p = reinterpret_cast<char*>(workspace);
+    NfWorkspace ws;
+    int* ints = reinterpret_cast<int*>(p);
+    ws.img = reinterpret_cast<NfImage*>(ints);
+    ws.stage_done = ints + 4 * B;
+    ws.count_after = ws.stage_done + (size_t)B * nchunk;
+    p += align256(nf_ints(B, K) * 4);
+    ws.deadK = reinterpret_cast<unsigned long long*>(p);
+    p += align256((size_t)B * 2 * NMS_CW * 8);
+    ws.maskT = reinterpret_cast<unsigned long long*>(p);
+    p += align256((size_t)B * 2 * NMS_CW * NMS_COLS * 8);
+    ws.maskR = reinterpret_cast<unsigned long long*>(p);
+    p += align256((size_t)B * 2 * NMS_CW * NMS_COLS * 8);
+    ws.sumT = reinterpret_cast<unsigned long long*>(p);
+    p += align256((size_t)B * 2 * NMS_CW * NMS_CW * 8);
+    ws.sumR = reinterpret_cast<unsigned long long*>(p);
+    p += align256((size_t)B * 2 * NMS_CW * NMS_CW * 8);
+    ws.keep_idx = reinterpret_cast<int32_t*>(p);
+    p += align256((size_t)B * post_n * 4);
+    ws.trace = reinterpret_cast<unsigned long long*>(p);
+    // worker workgroups: one per compute unit together with the resolvers (a stage of one image
+    // has up to 904 tiles for these 4,080 waves: one or two per SIMD)
+    int NW = 128 * B;
+    NW = NW > 256 - B ? 256 - B : NW;
+    // the counters and the kept words start from zero (one small launch; nothing else is read
+    // before it is written)
+    const int nzero = (int)(nf_ints(B, K) + (size_t)B * 2 * NMS_CW * 2);
+    static_assert(sizeof(unsigned long long) == 8, "deadK words are zeroed as pairs of ints");
+    FRCNN_LAUNCH(nms_fused_init_kernel, dim3(1), dim3(1024), 0, st, ints, (int)nf_ints(B, K));
+    FRCNN_LAUNCH(nms_fused_init_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<int*>(ws.deadK),
+                 B * 2 * NMS_CW * 2);
+    (void)nzero;
+    FRCNN_LAUNCH(nms_fused_kernel, dim3(B + NW), dim3(NF_THREADS), 0, st,
+                 reinterpret_cast<const float4*>(boxes), B, K, post_n, nchunk, NW, iou_threshold,
+                 1.0f + iou_threshold, iou_threshold * 0.999996f, ws,
+                 reinterpret_cast<float4*>(proposed), keep_pos, keep_count);
+    return FRCNN_OK;
 }
 
 // ---- the allocation-free variant: the NMS workspace is a device array of the code object.

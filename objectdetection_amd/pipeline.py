@@ -41,16 +41,34 @@ def _p(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+def _lib_tuning(key, default):
+    from ._lib import get_tuning
+    v = get_tuning(key)
+    return default if v is None else int(v)
+
+
 class RegionProposalPath:
     def __init__(self, cfg: PathConfig = REFERENCE, batch: int = 1, channels: int = 512,
                  device="cuda", train: bool = True, want_winner: bool = False,
                  fuse_pool: bool = True, depth: int = 1, topk: str = "sort",
-                 alloc_pooled: bool = True, fmap_planar: bool = False, rpn_targets: bool = True):
+                 alloc_pooled: bool = True, fmap_planar: bool = False, rpn_targets: bool = True,
+                 nms: str = "auto"):
         if depth not in (1, 2):
             raise ValueError("depth must be 1 or 2")
         if topk not in ("sort", "lds"):
             raise ValueError("topk must be 'sort' (radix sort, small workgroups) or 'lds'")
         self.topk = topk
+        if nms not in ("auto", "chunked", "fused"):
+            raise ValueError("nms must be 'auto', 'chunked' or 'fused'")
+        # one image at a time (the reference's inference call, model_train.py:741-743) is a chain
+        # of dependent launches in the chunked NMS: frcnn_nms_fused runs it as one launch.  From a
+        # few images on the chunked form wins (its mask tiles of all images run side by side).
+        if nms == "auto":
+            limit = _lib_tuning("nms_fused_max_b", 1)
+            nms = "fused" if depth == 1 and batch <= min(limit, ops.NMS_FUSED_MAX_B) else "chunked"
+        if nms == "fused" and batch > ops.NMS_FUSED_MAX_B:
+            raise ValueError(f"the one-launch NMS takes at most {ops.NMS_FUSED_MAX_B} images")
+        self.nms = nms
         self.cfg, self.B, self.C = cfg, batch, channels
         self.device = torch.device(device)
         self.train, self.fuse_pool, self.depth = train, fuse_pool, depth
@@ -84,7 +102,8 @@ class RegionProposalPath:
         self._sets = []
         for _ in range(depth):
             d = dict(top_scores=e((B, K), f32), top_idx=e((B, K), i32), cand=e((B, K, 4), f32),
-                     nms_ws=e((ops.nms_workspace_bytes(B, K, R),), u8),
+                     nms_ws=e((ops.nms_fused_workspace_bytes(B, K, R) if self.nms == "fused"
+                               else ops.nms_workspace_bytes(B, K, R),), u8),
                      topk_ws=e((ops.topk_sort_workspace_bytes(B, N) if topk == "sort" else 1,), u8),
                      proposed=e((B, R, 4), f32), keep_pos=e((B, R), i32), keep_count=e((B,), i32),
                      roi_ws=e((roi_ws_bytes,), u8),
@@ -206,7 +225,8 @@ class RegionProposalPath:
             prop.wait_event(ev[4])
         if nms_events is not None:
             nms_events[0].record(prop)
-        check("frcnn_nms", lib.frcnn_nms(
+        nms_fn = lib.frcnn_nms_fused if self.nms == "fused" else lib.frcnn_nms
+        check("frcnn_nms", nms_fn(
             _p(d["cand"]), B, cfg.pre_k, cfg.nms_thr, cfg.post_n, _p(d["proposed"]),
             _p(d["keep_pos"]), _p(d["keep_count"]), _p(d["nms_ws"]), d["nms_ws"].numel(), ps))
         if nms_events is not None:

@@ -48,6 +48,7 @@ HELPER_ENTRY_POINTS = (
     # stream-ordered halves / allocation-free variants used by RegionProposalPath and serving
     # loops directly; as operators they would be the ones above
     "frcnn_roi_fwd_prepare", "frcnn_roi_crop_pool_fwd_prepared", "frcnn_nms_static",
+    "frcnn_nms_fused", "frcnn_nms_fused_workspace_bytes",
 )
 
 

@@ -119,6 +119,10 @@ def test_config3_dense_100k_nms(dev):
     np.testing.assert_array_equal(cnt.cpu().numpy(), rc)
     np.testing.assert_array_equal(keep.cpu().numpy(), rk)
     np.testing.assert_array_equal(prop.cpu().numpy(), rp)
+    prop, keep, cnt = ops.nms_fused(T(boxes, dev), 0.7, post_n)        # the one-launch route
+    np.testing.assert_array_equal(cnt.cpu().numpy(), rc)
+    np.testing.assert_array_equal(keep.cpu().numpy(), rk)
+    np.testing.assert_array_equal(prop.cpu().numpy(), rp)
     # a tight cluster that forces the scan through all 1,563 column blocks
     c = 0.5 + rng.normal(0, 0.003, (K, 2))
     half = 0.2 + rng.normal(0, 0.002, (K, 2))
@@ -127,6 +131,9 @@ def test_config3_dense_100k_nms(dev):
     rp, rk, rc = O.combined_nms(dense, None, post_n, 0.7)
     assert rc[0] < post_n
     np.testing.assert_array_equal(keep.cpu().numpy(), rk)
+    _, keep_f, cnt_f = ops.nms_fused(T(dense, dev), 0.7, post_n)       # all 98 chunks, one launch
+    np.testing.assert_array_equal(keep_f.cpu().numpy(), rk)
+    assert int(cnt_f[0]) == rc[0]
     nms_properties(dense[0], keep[0].cpu().numpy(), int(cnt[0]), 0.7, post_n)
     # idempotence: NMS of the kept boxes keeps every one of them
     kept = rp[:, : rc[0]]

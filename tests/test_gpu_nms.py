@@ -27,6 +27,11 @@ def check(dev, boxes, thr, post_n):
     np.testing.assert_array_equal(cnt.cpu().numpy(), rc)
     np.testing.assert_array_equal(keep.cpu().numpy(), rk)
     np.testing.assert_array_equal(prop.cpu().numpy(), rp)
+    if boxes.shape[0] <= ops.NMS_FUSED_MAX_B:              # the one-launch route: same results
+        prop, keep, cnt = ops.nms_fused(T(boxes, dev), thr, post_n)
+        np.testing.assert_array_equal(cnt.cpu().numpy(), rc)
+        np.testing.assert_array_equal(keep.cpu().numpy(), rk)
+        np.testing.assert_array_equal(prop.cpu().numpy(), rp)
     return rc
 
 

@@ -200,3 +200,32 @@ def test_reference_named_functions_run_on_the_kept_buffer_sets(dev):
     assert torch.equal(prop2, path.proposed) and torch.equal(crop2, path.pooled)
     assert len(pipeline._PATH_CACHE) == 2              # the inference set is a second entry
     pipeline.clear_path_cache()
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_single_image_path_uses_the_one_launch_nms(dev, B):
+    """One 600x1000 image (the reference's inference call, model_train.py:741-743): the path
+    picks frcnn_nms_fused for one image, the chunked NMS from two on; both routes give the same
+    proposals, keep lists and pooled tensor, also as one HIP graph replay."""
+    import bench
+    from objectdetection_amd.pipeline import RegionProposalPath
+    cfg = bench.workload_cfg("600x1000")
+    C = 64
+    f, s, c, _, _ = bench.make_inputs(cfg, B, C, dev, seed=31 + B)
+    auto = RegionProposalPath(cfg, B, C, dev, train=False)
+    assert auto.nms == ("fused" if B == 1 else "chunked")
+    a = RegionProposalPath(cfg, B, C, dev, train=False, nms="fused")
+    b = RegionProposalPath(cfg, B, C, dev, train=False, nms="chunked")
+    a.run(f, s, c)
+    b.run(f, s, c)
+    torch.cuda.synchronize()
+    for k in ("proposed", "keep_pos", "keep_count", "pooled"):
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+    assert int(a.keep_count.min()) > 0
+    g = a.capture(f, s, c)
+    a.proposed.zero_(); a.keep_pos.zero_(); a.pooled.zero_()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    for k in ("proposed", "keep_pos", "keep_count", "pooled"):
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
