@@ -374,6 +374,20 @@ int frcnn_pad_gt(const float* boxes, const int64_t* labels, const int32_t* offse
 int frcnn_flip_images(const float* images, const uint8_t* flip, uint64_t seed, int image_base,
                       int B, int H, int W, int C, float* out, frcnn_stream_t stream);
 
+/* ---- next row f4: the head's first dense layer on the pooled tensor ---------------------------
+ * Replaces TimeDistributed(Flatten) + TimeDistributed(Dense(4096, activation='relu')),
+ * Faster_RCNN/module/model.py:31-32, on the tensor frcnn_roi_crop_pool_fwd writes: a RoI's
+ * [ph,pw,C] block IS its flattened (h,w,c) feature row, so x = pooled viewed as [M = B*R,
+ * K = ph*pw*C] and no transpose or copy sits between the pool and the GEMM.
+ * w [K,N] row-major (the Keras kernel layout), bias [N] (may be NULL), out [M,N];
+ * relu != 0 applies max(., 0).  float32 in and out on the float32 matrix cores
+ * (v_mfma_f32_32x32x2_f32): out[m][n] = act(fmaf-chain over k = 0..K-1 of x[m][k]*w[k][n],
+ * from 0, one rounding per product, + bias[n]) -- one accumulator per output, k ascending, no
+ * split over k, so the result does not depend on tile sizes.  K % 4 == 0, N % 4 == 0; x and w
+ * 16-byte aligned.  No workspace. */
+int frcnn_fc1_fwd(const float* x, const float* w, const float* bias, int64_t M, int K, int N,
+                  int relu, float* out, frcnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,6 +77,7 @@ _SIGS = {
     "frcnn_head_loss": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
     "frcnn_pad_gt": (_i, [_p, _p, _p, _p, _i, _u64, _i, _i, _i, _p, _p, _p, _p]),
     "frcnn_flip_images": (_i, [_p, _p, _u64, _i, _i, _i, _i, _i, _p, _p]),
+    "frcnn_fc1_fwd": (_i, [_p, _p, _p, _i64, _i, _i, _i, _p, _p]),
 }
 
 for _name, (_res, _args) in _SIGS.items():

@@ -1,0 +1,164 @@
+// The head's first dense layer on the pooled RoI tensor: out = relu(x W + b), float32 in, float32
+// accumulate, on the matrix cores (Faster_RCNN/module/model.py:31-32: TimeDistributed(Flatten)
+// followed by TimeDistributed(Dense(4096, relu)); x is the pooled tensor in the (h, w, c) order
+// the RoI kernels write, so Flatten is a view and no transpose sits between the two).
+//
+// gfx950 has float32-input MFMA (v_mfma_f32_32x32x2_f32: 32x32 outputs, two k per instruction,
+// 64 cycles per SIMD = 64 FLOP/clk/SIMD, the float32 vector rate).  Its result is a k-ordered
+// fmaf chain with one rounding per product, so with one accumulator per output element and k
+// walked upwards the GEMM is bit-identical to
+//     acc = 0; for k = 0 .. K-1: acc = fmaf(x[m][k], w[k][n], acc); out = max(acc + b[n], 0)
+// which is the layer's defined summation order.  There is no split over k for that reason.
+//
+// Workgroup = 128 x 128 outputs, four waves of 64 x 64 (2 x 2 MFMA blocks, 64 accumulator
+// registers); k in steps of 32 through two LDS buffers, the next step's tiles loaded to
+// registers while the current one is multiplied.  x rows are read as full 128-byte lines (8 lanes
+// per row) and transposed on their way into LDS (As[k][m], row stride 129 floats: the four
+// transposing 4-byte stores of a lane group and the row-contiguous fragment reads are both
+// conflict-free); W rows are copied as they are.  One fragment read per operand and MFMA block:
+// 4 LDS reads per 4 MFMAs (256 cycles), the LDS is idle 95 % of the time.
+//
+// Workgroup n runs on XCD n % 8.  Each XCD works through 8 x 8 super-tiles of workgroup tiles
+// (the 64 workgroups resident on its 32 CUs at two per CU): inside one, every x tile and every W
+// tile is read from HBM once and from that XCD's L2 seven more times.
+#include "frcnn_common.h"
+
+namespace frcnn {
+
+typedef float fc_f32x4 __attribute__((ext_vector_type(4)));
+typedef float fc_f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int FC_BM = 128, FC_BN = 128, FC_BK = 32;
+constexpr int FC_AS = FC_BM + 1;            // floats between k rows of the transposed x tile
+constexpr int FC_BS = FC_BN;                // floats between k rows of the W tile
+constexpr int FC_SUPER = 8;                 // workgroup tiles per super-tile edge
+
+__global__ void __launch_bounds__(256, 2)
+fc1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+               const float* __restrict__ bias, long long M, int K, int N, int relu,
+               int tiles_m, int tiles_n, float* __restrict__ out) {
+    // W tiles first (16-byte stores), then the transposed x tiles
+    extern __shared__ __attribute__((aligned(16))) float fc_lds[];
+    float (*Bs)[FC_BK * FC_BS] = reinterpret_cast<float (*)[FC_BK * FC_BS]>(fc_lds);
+    float (*As)[FC_BK * FC_AS] = reinterpret_cast<float (*)[FC_BK * FC_AS]>(fc_lds + 2 * FC_BK * FC_BS);
+    int tm, tn;
+    {
+        const int SN = (tiles_n + FC_SUPER - 1) / FC_SUPER;
+        const int SM = (tiles_m + FC_SUPER - 1) / FC_SUPER;
+        const int id = (int)blockIdx.x, xcd = id & 7, local = id >> 3;
+        const int super = (local >> 6) * 8 + xcd, within = local & 63;
+        if (super >= SM * SN) return;
+        tm = (super / SN) * FC_SUPER + (within >> 3);
+        tn = (super % SN) * FC_SUPER + (within & 7);
+        if (tm >= tiles_m || tn >= tiles_n) return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const long long m_base = (long long)tm * FC_BM;
+    const int n_base = tn * FC_BN;
+
+    // global -> register staging: four 16-byte pieces of each operand per thread
+    // x tile: piece idx = tid + 256 i -> row idx / 8, floats 4 (idx % 8) .. +3 of the k step
+    // W tile: piece idx -> k row idx / 32, floats 4 (idx % 32) .. +3
+    fc_f32x4 ra[4], rb[4];
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            const int am = idx >> 3, ak = k0 + 4 * (idx & 7);
+            const long long gm = m_base + am;
+            ra[i] = fc_f32x4{0.f, 0.f, 0.f, 0.f};
+            if (gm < M && ak < K)
+                ra[i] = *reinterpret_cast<const fc_f32x4*>(x + (size_t)gm * (size_t)K + ak);
+            const int bk = k0 + (idx >> 5), bn = n_base + 4 * (idx & 31);
+            rb[i] = fc_f32x4{0.f, 0.f, 0.f, 0.f};
+            if (bk < K && bn < N)
+                rb[i] = *reinterpret_cast<const fc_f32x4*>(w + (size_t)bk * (size_t)N + bn);
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            const int am = idx >> 3, ak = 4 * (idx & 7);
+            float* a = &As[buf][ak * FC_AS + am];
+            a[0] = ra[i].x; a[FC_AS] = ra[i].y; a[2 * FC_AS] = ra[i].z; a[3 * FC_AS] = ra[i].w;
+            *reinterpret_cast<fc_f32x4*>(&Bs[buf][(idx >> 5) * FC_BS + 4 * (idx & 31)]) = rb[i];
+        }
+    };
+
+    fc_f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nt = (K + FC_BK - 1) / FC_BK;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    const int half = lane >> 5, r32 = lane & 31;
+#pragma unroll 1
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) load_tiles((t + 1) * FC_BK);
+        const float* as = &As[buf][half * FC_AS + wm * 64 + r32];
+        const float* bs = &Bs[buf][half * FC_BS + wn * 64 + r32];
+#pragma unroll
+        for (int kk = 0; kk < FC_BK; kk += 2) {
+            const float a0 = as[kk * FC_AS], a1 = as[kk * FC_AS + 32];
+            const float b0 = bs[kk * FC_BS], b1 = bs[kk * FC_BS + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (t + 1 < nt) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // accumulator element r of a lane: column lane & 31, row (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n_base + wn * 64 + j * 32 + r32;
+        if (col >= N) continue;
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long row = m_base + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row >= M) continue;
+                float v = acc[i][j][r];
+                if (bias) v = v + bv;
+                if (relu) v = v > 0.f ? v : 0.f;
+                out[(size_t)row * (size_t)N + col] = v;
+            }
+    }
+}
+
+}  // namespace frcnn
+
+using namespace frcnn;
+
+extern "C" int frcnn_fc1_fwd(const float* x, const float* w, const float* bias, int64_t M, int K,
+                             int N, int relu, float* out, frcnn_stream_t stream) {
+    if (!x || !w || !out || M <= 0 || K <= 0 || N <= 0) return FRCNN_E_BADARG;
+    if ((K % 4) != 0 || (N % 4) != 0) return FRCNN_E_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(x) % 16) || (reinterpret_cast<uintptr_t>(w) % 16))
+        return FRCNN_E_BADARG;
+    const long long tiles_m = (M + FC_BM - 1) / FC_BM, tiles_n = (N + FC_BN - 1) / FC_BN;
+    const long long SM = (tiles_m + FC_SUPER - 1) / FC_SUPER, SN = (tiles_n + FC_SUPER - 1) / FC_SUPER;
+    const long long groups = (SM * SN + 7) / 8;
+    const long long blocks = groups * 8 * FC_SUPER * FC_SUPER;
+    if (tiles_m > 0x7FFFFF || tiles_n > 0x7FFFFF || blocks > 0x7FFFFFFFll) return FRCNN_E_UNSUPPORTED;
+    constexpr size_t lds = (size_t)2 * FC_BK * (FC_AS + FC_BS) * sizeof(float);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fc1_fwd_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return FRCNN_E_LAUNCH;
+    FRCNN_LAUNCH(fc1_fwd_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, x, w, bias,
+                 (long long)M, K, N, relu, (int)tiles_m, (int)tiles_n, out);
+    return FRCNN_OK;
+}

@@ -102,3 +102,14 @@ class _RoICropPool(torch.autograd.Function):
 def roi_pool_autograd(fmap: torch.Tensor, proposed: torch.Tensor, cfg: PathConfig = REFERENCE):
     """roi_pool with a backward pass to the feature map (for end-to-end training)."""
     return _RoICropPool.apply(fmap, proposed, tuple(cfg.crop), int(cfg.pool))
+
+
+def fc1(pooled: torch.Tensor, kernel: torch.Tensor, bias: Optional[torch.Tensor] = None,
+        relu: bool = True) -> torch.Tensor:
+    """The first two layers of the head behind the RoI pool (module/model.py:31-32):
+    TimeDistributed(Flatten) + TimeDistributed(Dense(4096, activation='relu')).
+
+    pooled [B,R,7,7,C] as process_fmap(fuse_pool=True) / roi_pool return it: a RoI's block is
+    its (h,w,c)-flattened row already, so Flatten is a view.  kernel [7*7*C, units] and bias
+    [units] in the Keras layout.  Returns [B,R,units] float32, computed by frcnn_fc1_fwd."""
+    return ops.fc1_fwd(pooled, kernel, bias, relu)

@@ -16,7 +16,7 @@ from ._lib import lib, check
 __all__ = [
     "anchors", "iou_assign", "rpn_sample", "encode", "decode_clip", "topk", "nms",
     "nms_workspace_bytes", "roi_crop_pool_fwd", "roi_crop_pool_bwd", "label_proposals",
-    "sample_proposals", "detect_postprocess",
+    "sample_proposals", "detect_postprocess", "fc1_fwd",
 ]
 
 
@@ -504,3 +504,34 @@ def flip_images(images: torch.Tensor, flip: Optional[torch.Tensor] = None, seed:
             _ptr(im), _ptr(fl), seed & 0xFFFFFFFFFFFFFFFF, image_base, B, H, W, Cc, _ptr(out),
             _stream(im)))
     return out
+
+
+def fc1_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+            relu: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The head's first dense layer (frcnn_fc1_fwd; module/model.py:31-32).
+
+    x [..., K] float32 (the pooled tensor [B,R,ph,pw,C] is taken as [B*R, ph*pw*C], a view),
+    weight [K,N] (Keras kernel layout), bias [N] or None -> [..., N] = act(x @ weight + bias)."""
+    w = _cont(weight, "weight", torch.float32)
+    if w.dim() != 2:
+        raise ValueError("weight must be [K,N]")
+    K, N = w.shape
+    xx = _cont(x, "x", torch.float32)
+    if xx.dim() == 5:                                  # pooled [B,R,ph,pw,C]
+        lead = tuple(xx.shape[:2])
+        xx = xx.reshape(lead[0] * lead[1], -1)
+    else:
+        lead = tuple(xx.shape[:-1])
+        xx = xx.reshape(-1, xx.shape[-1])
+    if xx.shape[1] != K:
+        raise ValueError(f"x has {xx.shape[1]} features per row, weight expects {K}")
+    b = None if bias is None else _cont(bias, "bias", torch.float32).reshape(N)
+    M = xx.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=xx.device)
+    elif out.dtype != torch.float32 or out.numel() != M * N or not out.is_contiguous():
+        raise ValueError("out must be a contiguous float32 tensor of M*N elements")
+    with torch.cuda.device(xx.device):
+        check("frcnn_fc1_fwd", lib.frcnn_fc1_fwd(_ptr(xx), _ptr(w), _ptr(b), M, K, N, int(bool(relu)),
+                                                 _ptr(out), _stream(xx)))
+    return out.view(*lead, N)

@@ -40,6 +40,7 @@ OP_ENTRY_POINTS = {
     "head_loss": ("frcnn_head_loss",),
     "pad_gt": ("frcnn_pad_gt",),
     "flip_images": ("frcnn_flip_images",),
+    "fc1": ("frcnn_fc1_fwd",),
 }
 HELPER_ENTRY_POINTS = (
     "frcnn_abi_version", "frcnn_status_string", "frcnn_set_tuning", "frcnn_get_tuning",
@@ -324,6 +325,20 @@ def flip_images(images: Tensor, seed: int, image_base: int) -> Tensor:
 @flip_images.register_fake
 def _(images, seed, image_base):
     return torch.empty_like(images)
+
+
+# ---- f4 ---------------------------------------------------------------------------------------
+@_op("fc1")
+def fc1(x: Tensor, weight: Tensor, bias: Tensor, relu: bool) -> Tensor:
+    """x [M,K] (or the pooled tensor [B,R,ph,pw,C]), weight [K,N], bias [N] -> act(x W + b)
+    on the float32 matrix cores (module/model.py:31-32).  Forward only."""
+    return ops.fc1_fwd(x, weight, bias, relu)
+
+
+@fc1.register_fake
+def _(x, weight, bias, relu):
+    lead = tuple(x.shape[:2]) if x.dim() == 5 else tuple(x.shape[:-1])
+    return _e(x, lead + (weight.shape[1],))
 
 
 OPS = tuple(OP_ENTRY_POINTS)

@@ -84,3 +84,18 @@ def roi_crop_pool_bwd(lib, dY, winner, rois, fmap_hwc, crop=(14, 14), pool=2):
     lib.oc_roi_crop_pool_bwd(_p(g), _p(w) if w is not None else None, _p(r), r.shape[0], H, W, Cc,
                              crop[0], crop[1], pool, _p(out))
     return out
+
+
+def fc1(lib, x, w, bias=None, relu=True):
+    """x [M,K], w [K,N], bias [N] | None -> act(x w + bias) as the k-ordered fmaf chain."""
+    xx = np.ascontiguousarray(x, np.float32)
+    xx = xx.reshape(-1, xx.shape[-1])
+    ww = np.ascontiguousarray(w, np.float32)
+    M, K = xx.shape
+    N = ww.shape[1]
+    assert ww.shape[0] == K
+    b = None if bias is None else np.ascontiguousarray(bias, np.float32).reshape(N)
+    out = np.empty((M, N), np.float32)
+    lib.oc_fc1(_p(xx), _p(ww), _p(b) if b is not None else None, C.c_long(M), K, N, int(bool(relu)),
+               _p(out))
+    return out

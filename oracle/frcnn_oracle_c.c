@@ -214,3 +214,48 @@ void oc_roi_crop_pool_bwd(const float* dY, const uint8_t* winner, const float* r
         }
     }
 }
+
+/* ---- next row f4: Flatten + Dense(4096, relu), Faster_RCNN/module/model.py:31-32 -------------
+ * out[m][n] = act(acc + bias[n]), acc = a k-ordered chain of fused multiply-adds from 0:
+ * acc = fmaf(x[m][k], w[k][n], acc) for k = 0 .. K-1 (one rounding per product).  That chain is
+ * the build-defined summation order of the layer (TensorFlow's MatMul leaves the order to its
+ * BLAS); it is what the float32 matrix instruction computes.  The body is built twice: with the
+ * FMA instruction set where the host has it (fmaf inlines, the n loop vectorises) and through
+ * libm's fmaf otherwise -- the same values either way. */
+#define OC_FC1_BODY                                                                              \
+    for (long m = 0; m < M; ++m) {                                                               \
+        float* o = out + (size_t)m * N;                                                          \
+        for (int n = 0; n < N; ++n) o[n] = 0.0f;                                                 \
+        for (int k = 0; k < K; ++k) {                                                            \
+            const float a = x[(size_t)m * K + k];                                                \
+            const float* wr = w + (size_t)k * N;                                                 \
+            for (int n = 0; n < N; ++n) o[n] = __builtin_fmaf(a, wr[n], o[n]);                   \
+        }                                                                                        \
+        for (int n = 0; n < N; ++n) {                                                            \
+            float v = o[n];                                                                      \
+            if (bias) v = v + bias[n];                                                           \
+            if (relu) v = v > 0.0f ? v : 0.0f;                                                   \
+            o[n] = v;                                                                            \
+        }                                                                                        \
+    }
+#if defined(__x86_64__)
+__attribute__((target("fma,avx2"))) static void oc_fc1_fma(const float* x, const float* w,
+                                                           const float* bias, long M, int K, int N,
+                                                           int relu, float* out) {
+    OC_FC1_BODY
+}
+#endif
+static void oc_fc1_libm(const float* x, const float* w, const float* bias, long M, int K, int N,
+                        int relu, float* out) {
+    OC_FC1_BODY
+}
+void oc_fc1(const float* x, const float* w, const float* bias, long M, int K, int N, int relu,
+            float* out) {
+#if defined(__x86_64__)
+    if (__builtin_cpu_supports("fma") && __builtin_cpu_supports("avx2")) {
+        oc_fc1_fma(x, w, bias, M, K, N, relu, out);
+        return;
+    }
+#endif
+    oc_fc1_libm(x, w, bias, M, K, N, relu, out);
+}

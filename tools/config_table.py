@@ -136,6 +136,21 @@ def main():
     t = timed(lambda: ops.flip_images(imgs, seed=3), reps=5)
     t["GBps_read_plus_write"] = 2 * imgs.numel() * 4 / (t["mean_ms"] * 1e-3) / 1e9
     res["next_flip_images_B64_600x1000x3"] = t
+    del imgs
+    # the head's first dense layer on the pooled tensor of a batch-8 step: [16,000, 25,088] x
+    # [25,088, 4,096], float32 matrix cores (peak 157.3 TFLOP/s); torch.matmul beside it
+    Mr, Kf, Nf = 8 * cfg1.post_n, 7 * 7 * 512, 4096
+    xf = torch.relu(torch.randn((Mr, Kf), generator=g, device=dev))
+    wf = torch.randn((Kf, Nf), generator=g, device=dev) * 0.01
+    bf = torch.randn((Nf,), generator=g, device=dev)
+    of = torch.empty((Mr, Nf), device=dev)
+    t = timed(lambda: ops.fc1_fwd(xf, wf, bf, True, out=of), reps=3, warm=1)
+    t["tflops"] = 2.0 * Mr * Kf * Nf / (t["mean_ms"] * 1e-3) / 1e12
+    t["frac_of_f32_mfma_peak"] = t["tflops"] / 157.3
+    res["next_fc1_16000x25088x4096"] = t
+    t = timed(lambda: torch.relu_(torch.addmm(bf, xf, wf, out=of)), reps=3, warm=1)
+    t["tflops"] = 2.0 * Mr * Kf * Nf / (t["mean_ms"] * 1e-3) / 1e12
+    res["next_fc1_torch_addmm_relu"] = t
     txt = json.dumps(res, indent=1)
     print(txt)
     if len(sys.argv) > 1:

@@ -28,11 +28,16 @@ kbase = kernel.split("<")[0]                   # the step's RoI kernel (others o
 vals = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(os.path.join(src, f"pmc_{c}", "*", "*counter_collection.csv"))[0]
-    per = {}
+    per, grid = {}, {}
     for r in csv.DictReader(open(f)):
         if kbase in r["Kernel_Name"] and r["Counter_Name"] == c:
             per[r["Dispatch_Id"]] = per.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
-    vals[c] = sum(per.values()) / len(per)
+            grid[r["Dispatch_Id"]] = int(r["Grid_Size"])
+    # the headline workload's launches only (the bench line's secondary block and its
+    # single-image section launch the same kernel on smaller grids)
+    big = max(grid.values())
+    sel = [v for d, v in per.items() if grid[d] == big]
+    vals[c] = sum(sel) / len(sel)
 rec = {
     "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py workload, {tag}",
     "fetch_size_kb": vals["FETCH_SIZE"], "write_size_kb": vals["WRITE_SIZE"],
@@ -41,7 +46,14 @@ rec = {
 }
 path = os.path.join(dst, "roi_fwd_traffic.json")
 doc = json.load(open(path)) if os.path.exists(path) else {}
-doc.update(batch=bench["config"]["images_per_gpu_per_step"], channels=512, config="600x1000")
+sys.path.insert(0, ROOT)
+import bench as _bench  # noqa: E402
+doc.update(batch=bench["config"]["images_per_gpu_per_step"], channels=512, config="600x1000",
+           csrc_sha=bench.get("kernel_sources_sha"),
+           commit=subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"],
+                                 capture_output=True, text=True).stdout.strip())
+if doc["csrc_sha"] != _bench.sources_sha():
+    print(f"note: collected on {doc['csrc_sha']}, the tree is now {_bench.sources_sha()}")
 old = doc.setdefault("kernels", {}).get(kernel, {})
 if "co_bounds" in old:
     rec["co_bounds"] = old["co_bounds"]            # hand-written floors stay with the kernel
