@@ -60,10 +60,12 @@ const char* frcnn_status_string(int status);
  *   "nms_gk"            FRCNN_NMS_GK            mask workgroups per column block (<= 0: by batch)
  *   "roi_band_min_wg"   FRCNN_ROI_BAND_MIN_WG   band-resident RoI forward from n workgroups on and
  *                                               for any RoI count (n < 0: never)
- *   "bwd_cx"            FRCNN_BWD_CX            feature cells per wave of the gather backward (1|2)
+ *   "bwd_cx"            FRCNN_BWD_CX            gather backward: feature cells per wave (1|2);
+ *                                               patch-owner backward: patch shape, 10 * rows +
+ *                                               columns (44|34|46|26; default by launch size)
  *   "bwd_chunk"         FRCNN_BWD_CHUNK         RoIs per launch of the gather backward (<= 0: by batch)
- *   "bwd_band"          FRCNN_BWD_BAND          band-owner RoI backward: 1 always (when the sizes
- *                                               allow), 0 never
+ *   "bwd_band"          FRCNN_BWD_BAND          patch-owner RoI backward (pool 2, crops up to
+ *                                               16 x 16): 0 never (the gather kernel runs instead)
  *   "nms_fused_max_b"   FRCNN_NMS_FUSED_MAX_B   single-launch NMS for batches up to n images
  * A variable present in the environment when the library is loaded gives the initial value;
  * frcnn_set_tuning replaces it (FRCNN_TUNING_UNSET restores the built-in choice).  Returns

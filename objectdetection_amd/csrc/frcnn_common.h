@@ -33,9 +33,10 @@ namespace frcnn {
 enum Tuning {
     TUNE_NMS_GK = 0,          // FRCNN_NMS_GK: mask workgroups per column block (0 = by batch size)
     TUNE_ROI_BAND_MIN_WG,     // FRCNN_ROI_BAND_MIN_WG: band kernel from n workgroups on (< 0: never)
-    TUNE_BWD_CX,              // FRCNN_BWD_CX: feature cells per wave of the gather backward (1 | 2)
+    TUNE_BWD_CX,              // FRCNN_BWD_CX: gather backward: feature cells per wave (1 | 2); patch-owner
+                              // backward: patch shape 10 * rows + columns (44 | 34 | 46 | 26)
     TUNE_BWD_CHUNK,           // FRCNN_BWD_CHUNK: RoIs per backward launch (0 = by batch size)
-    TUNE_BWD_BAND,            // FRCNN_BWD_BAND: band-owner backward (1 on, 0 off, unset = by size)
+    TUNE_BWD_BAND,            // FRCNN_BWD_BAND: patch-owner backward (0: off, the gather kernel runs; else on)
     TUNE_NMS_FUSED_MAX_B,     // FRCNN_NMS_FUSED_MAX_B: one-launch NMS up to this many images
     TUNE_COUNT
 };
@@ -318,5 +319,44 @@ __device__ __forceinline__ void axis_sample(float c1, float c2, int dim, int n, 
     lo = ok ? (int)f : 0;
     hi = ok ? (int)c : 0;
 }
+
+// ---- wave-uniform reads of one lane
+__device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ float rlf(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+
+// The source coordinate of sample s is base + s * scale (axis_sample's expression): base and
+// scale depend on the box only, so the lane that tests a RoI as a candidate computes them (one
+// division) and the lanes that evaluate its samples later take them by readlane.
+__device__ __forceinline__ void axis_line(float c1, float c2, int dim, int n, float& base,
+                                          float& scale) {
+    if (n > 1) {
+        scale = ((c2 - c1) * (float)(dim - 1)) / (float)(n - 1);
+        base = c1 * (float)(dim - 1);
+    } else {
+        scale = 0.0f;
+        base = (float)(0.5 * (double)(c1 + c2) * (double)(dim - 1));
+    }
+}
+__device__ __forceinline__ bool line_reaches(float base, float scale, int n, int t0, int t1) {
+    const float last = n > 1 ? base + (float)(n - 1) * scale : base;
+    const float lo = floorf(fminf(base, last)), hi = ceilf(fmaxf(base, last));
+    return (float)t1 >= lo && (float)t0 <= hi;              // NaN -> false
+}
+__device__ __forceinline__ void line_sample(float base, float scale, int dim, int n, int s, int& lo,
+                                            int& hi, float& frac, int& ok) {
+    const float in = n > 1 ? base + (float)s * scale : base;
+    ok = (in >= 0.0f && in <= (float)(dim - 1));      // NaN -> extrapolated
+    const float f = floorf(in), c = ceilf(in);
+    frac = in - f;
+    lo = ok ? (int)f : 0;
+    hi = ok ? (int)c : 0;
+}
+
+// RoI backward, patch-owner form (frcnn_roi_bwd.hip); FRCNN_E_UNSUPPORTED when the shape is not its
+int launch_roi_bwd_patch(const float* dY, const uint8_t* winner, const float* rois, int B, int R, int H,
+                         int W, int C, int crop_h, int crop_w, float* dfmap, hipStream_t stream);
 
 }  // namespace frcnn

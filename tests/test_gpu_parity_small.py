@@ -264,6 +264,32 @@ def test_roi_backward_in_ranges_of_rois(dev, chunk, cx, tuning):
     np.testing.assert_array_equal(got.cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("shape", [44, 34, 46, 26])
+def test_roi_backward_patch_shapes(dev, shape, tuning):
+    """The patch-owner backward picks its patch shape by launch size; every shape is forced here
+    (ragged map edges in both directions, boxes reaching beyond the image, two channel slices,
+    one of them partly beyond C): the sums must not depend on it."""
+    from objectdetection_amd import ops
+    tuning("bwd_band", 1)
+    tuning("bwd_cx", int(shape))
+    rng = np.random.default_rng(shape)
+    B, H, W, C, R = 2, 13, 17, 320, 130
+    fm = np.maximum(rng.standard_normal((B, H, W, C)).astype(np.float32), 0)
+    y1 = rng.uniform(-0.05, 0.7, (B, R)); x1 = rng.uniform(-0.05, 0.7, (B, R))
+    prop = np.stack([y1, x1, y1 + rng.uniform(0.02, 0.6, (B, R)), x1 + rng.uniform(0.02, 0.6, (B, R))],
+                    -1).astype(np.float32)
+    prop[0, 3] = [0.0, 0.0, 1.0, 1.0]                  # samples exactly on feature rows / columns
+    prop[0, 4] = [0.25, 0.25, 0.25, 0.25]              # a point: every sample in one place
+    prop[1, 5] = [0.0, 0.0, 0.0, 0.0]                  # the zero padding of the proposal list
+    for crop in ((14, 14), (16, 12)):
+        out, win = ops.roi_crop_pool_fwd(T(fm, dev), T(prop, dev), crop, 2, want_winner=True)
+        ro, ra = O.roi_crop_pool(fm, prop, crop, 2)
+        dY = rng.standard_normal(ro.shape).astype(np.float32)
+        got = ops.roi_crop_pool_bwd(T(dY, dev), win, T(prop, dev), fm.shape, crop, 2)
+        ref = O.roi_crop_pool_bwd(dY, ra, fm.shape, prop, crop, 2)
+        np.testing.assert_array_equal(got.cpu().numpy(), ref)
+
+
 @pytest.mark.parametrize("mode", ["keys", "philox"])
 def test_making_frcnn_input(dev, ref_inputs, mode):
     from objectdetection_amd import ops

@@ -55,9 +55,14 @@ def test_backward_kernels_do_not_spill(budgets):
             assert k["scratch"] == 0, (name, k)
     # C = 512: two channel quads per lane, crops up to 16 x 16
     assert budgets["roi_bwd_wave_kernel<2,2,16,2>"]["vgpr"] <= 128
-    for name, k in budgets.items():
-        if name.startswith("roi_bwd_band_kernel<"):
-            assert k["scratch"] == 0 and k["vgpr"] <= 128, (name, k)
+    # patch-owner backward: the sums sit in pinned registers (v64 up), nothing may spill, and
+    # the two default shapes must leave room for three waves per SIMD
+    patch = {n: k for n, k in budgets.items() if n.startswith("roi_bwd_patch_kernel<")}
+    assert patch, "roi_bwd_patch_kernel is missing from the library"
+    for name, k in patch.items():
+        assert k["scratch"] == 0 and k["lds"] == 0, (name, k)
+    for name in ("roi_bwd_patch_kernel<4,4,3>", "roi_bwd_patch_kernel<3,4,3>"):
+        assert patch[name]["vgpr"] <= 168, (name, patch[name])
 
 
 def test_target_kernels_fit_beside_a_band_workgroup(budgets):
