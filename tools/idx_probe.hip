@@ -38,6 +38,8 @@ __global__ void __launch_bounds__(256) timing(float* out, long long* cyc, int n,
     f32x2 g0 = {1.f + threadIdx.x, 2.f}, g1 = {3.f, 4.f};
     const long long t0 = __builtin_amdgcn_s_memtime();
     for (int j = 0; j < n; ++j) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
         if (MODE == 0)
             asm volatile(
                 "v_pk_add_f32 v[96:97], v[96:97], %[g0]\nv_pk_add_f32 v[98:99], v[98:99], %[g1]\n"
@@ -69,6 +71,7 @@ __global__ void __launch_bounds__(256) timing(float* out, long long* cyc, int n,
                 "v_pk_add_f32 v[96:97], v[96:97], %[g0]\nv_pk_add_f32 v[98:99], v[98:99], %[g1]\n"
                 "s_set_gpr_idx_off\n"
                 : ACCOPS(acc) : [i0] "s"(i0), [i1] "s"(i1), [i2] "s"(i2), [i3] "s"(i3), [g0] "v"(g0), [g1] "v"(g1));
+      }
     }
     const long long t1 = __builtin_amdgcn_s_memtime();
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
@@ -92,18 +95,20 @@ int main() {
     int bad = 0;
     for (size_t i = 0; i < outh.size(); ++i) if (outh[i] != ref[i]) ++bad;
     printf("idx-mode test: %d mismatches of %zu\n", bad, outh.size());
-    const int N = 20000;
-    long long c[3];
-    for (int rep = 0; rep < 2; ++rep) {
-        hipLaunchKernelGGL(timing<0>, dim3(1), dim3(256), 0, 0, dout, dcyc, N, 0, 4, 24, 28);
-        hipMemcpy(&c[0], dcyc, 8, hipMemcpyDeviceToHost);
-        hipLaunchKernelGGL(timing<1>, dim3(1), dim3(256), 0, 0, dout, dcyc, N, 0, 4, 24, 28);
-        hipMemcpy(&c[1], dcyc, 8, hipMemcpyDeviceToHost);
-        hipLaunchKernelGGL(timing<2>, dim3(1), dim3(256), 0, 0, dout, dcyc, N, 0, 4, 24, 28);
-        hipMemcpy(&c[2], dcyc, 8, hipMemcpyDeviceToHost);
+    const int N = 5000;                                    // x 4 groups per iteration
+    for (int waves = 1; waves <= 1; ++waves) {   // the pinned v[96:255] allow one wave per SIMD
+        long long c[3];
+        for (int rep = 0; rep < 2; ++rep) {
+            hipLaunchKernelGGL(timing<0>, dim3(1), dim3(256 * waves), 0, 0, dout, dcyc, N, 0, 4, 24, 28);
+            hipMemcpy(&c[0], dcyc, 8, hipMemcpyDeviceToHost);
+            hipLaunchKernelGGL(timing<1>, dim3(1), dim3(256 * waves), 0, 0, dout, dcyc, N, 0, 4, 24, 28);
+            hipMemcpy(&c[1], dcyc, 8, hipMemcpyDeviceToHost);
+            hipLaunchKernelGGL(timing<2>, dim3(1), dim3(256 * waves), 0, 0, dout, dcyc, N, 0, 4, 24, 28);
+            hipMemcpy(&c[2], dcyc, 8, hipMemcpyDeviceToHost);
+        }
+        // s_memtime ticks per group of 8 v_pk_add_f32, divided by the waves sharing the SIMD
+        printf("%d wave(s) per SIMD, ticks per group of 8 pk_add and wave: fixed %.1f, one region + 3 idx %.1f, four regions %.1f\n",
+               waves, (double)c[0] / (4.0 * N * waves), (double)c[1] / (4.0 * N * waves), (double)c[2] / (4.0 * N * waves));
     }
-    // s_memtime counts at 100 MHz on this part: report ns per group
-    printf("per group of 8 pk_add (one wave per SIMD): fixed %.1f ns, one region + 3 idx %.1f ns, four regions %.1f ns\n",
-           c[0] * 10.0 / N, c[1] * 10.0 / N, c[2] * 10.0 / N);
     return bad != 0;
 }
