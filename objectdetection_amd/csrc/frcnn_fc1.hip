@@ -16,7 +16,10 @@
 // per row) and transposed on their way into LDS (As[k][m], row stride 129 floats: the four
 // transposing 4-byte stores of a lane group and the row-contiguous fragment reads are both
 // conflict-free); W rows are copied as they are.  One fragment read per operand and MFMA block:
-// 4 LDS reads per 4 MFMAs (256 cycles), the LDS is idle 95 % of the time.
+// 4 LDS reads per 4 MFMAs (256 cycles), issued one k pair ahead of the MFMAs that use them (the
+// four MFMAs of a pair take ~190 cycles to issue, so a read issued behind them and waited for
+// right away stalled the wave: 117 -> 125 TFLOP/s).  k steps of 16 with three or four workgroups
+// per compute unit instead of two measured the same (FRCNN_FC_BK / FRCNN_FC_WGS).
 //
 // Workgroup n runs on XCD n % 8.  Each XCD works through 8 x 8 super-tiles of workgroup tiles
 // (the 64 workgroups resident on its 32 CUs at two per CU): inside one, every x tile and every W
@@ -28,12 +31,20 @@ namespace frcnn {
 typedef float fc_f32x4 __attribute__((ext_vector_type(4)));
 typedef float fc_f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int FC_BM = 128, FC_BN = 128, FC_BK = 32;
+#ifndef FRCNN_FC_BK
+#define FRCNN_FC_BK 32
+#endif
+#ifndef FRCNN_FC_WGS
+#define FRCNN_FC_WGS 2
+#endif
+constexpr int FC_BM = 128, FC_BN = 128, FC_BK = FRCNN_FC_BK;
+constexpr int FC_NP = FC_BK / 8;            // 16-byte pieces of each operand tile per thread
+constexpr int FC_RP = FC_BK / 4;            // pieces per x row of a k step
 constexpr int FC_AS = FC_BM + 1;            // floats between k rows of the transposed x tile
 constexpr int FC_BS = FC_BN;                // floats between k rows of the W tile
 constexpr int FC_SUPER = 8;                 // workgroup tiles per super-tile edge
 
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, FRCNN_FC_WGS)
 fc1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                const float* __restrict__ bias, long long M, int K, int N, int relu,
                int tiles_m, int tiles_n, float* __restrict__ out) {
@@ -60,12 +71,12 @@ fc1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
     // global -> register staging: four 16-byte pieces of each operand per thread
     // x tile: piece idx = tid + 256 i -> row idx / 8, floats 4 (idx % 8) .. +3 of the k step
     // W tile: piece idx -> k row idx / 32, floats 4 (idx % 32) .. +3
-    fc_f32x4 ra[4], rb[4];
+    fc_f32x4 ra[FC_NP], rb[FC_NP];
     auto load_tiles = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < FC_NP; ++i) {
             const int idx = tid + 256 * i;
-            const int am = idx >> 3, ak = k0 + 4 * (idx & 7);
+            const int am = idx / FC_RP, ak = k0 + 4 * (idx % FC_RP);
             const long long gm = m_base + am;
             ra[i] = fc_f32x4{0.f, 0.f, 0.f, 0.f};
             if (gm < M && ak < K)
@@ -78,9 +89,9 @@ fc1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
     };
     auto store_tiles = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < FC_NP; ++i) {
             const int idx = tid + 256 * i;
-            const int am = idx >> 3, ak = 4 * (idx & 7);
+            const int am = idx / FC_RP, ak = 4 * (idx % FC_RP);
             float* a = &As[buf][ak * FC_AS + am];
             a[0] = ra[i].x; a[FC_AS] = ra[i].y; a[2 * FC_AS] = ra[i].z; a[3 * FC_AS] = ra[i].w;
             *reinterpret_cast<fc_f32x4*>(&Bs[buf][(idx >> 5) * FC_BS + 4 * (idx & 31)]) = rb[i];
@@ -106,14 +117,23 @@ fc1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
         if (t + 1 < nt) load_tiles((t + 1) * FC_BK);
         const float* as = &As[buf][half * FC_AS + wm * 64 + r32];
         const float* bs = &Bs[buf][half * FC_BS + wn * 64 + r32];
+        // fragments one k pair ahead: the reads of pair kk + 2 are issued in front of the four
+        // MFMAs of pair kk, whose issue alone takes ~190 cycles, so the wait that follows is short
+        float a0 = as[0], a1 = as[32], b0 = bs[0], b1 = bs[32];
 #pragma unroll
         for (int kk = 0; kk < FC_BK; kk += 2) {
-            const float a0 = as[kk * FC_AS], a1 = as[kk * FC_AS + 32];
-            const float b0 = bs[kk * FC_BS], b1 = bs[kk * FC_BS + 32];
+            float na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
+            if (kk + 2 < FC_BK) {
+                na0 = as[(kk + 2) * FC_AS]; na1 = as[(kk + 2) * FC_AS + 32];
+                nb0 = bs[(kk + 2) * FC_BS]; nb1 = bs[(kk + 2) * FC_BS + 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
         }
         if (t + 1 < nt) store_tiles(buf ^ 1);
         __syncthreads();
