@@ -33,6 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak
+F32_MFMA_PEAK_TFLOPS = 157.3   # dense float32 matrix peak (v_mfma_f32_32x32x2_f32)
 
 WORKLOADS = {
     # 600x1000 image, VGG16 stride 16 -> 37x62 map, 9 anchors (20,646), G=42, 12k -> 2k NMS at
@@ -183,6 +184,45 @@ def single_image(cfg, C, device, seed=4242):
                 nms_us_single_image_chunked=chunked_ms * 1e3, roi_us_single_image=roi_ms * 1e3,
                 kept=int(path.keep_count[0]),
                 note="one 600x1000 image, inference stages (top-k, NMS, RoI crop + pool), idle chip")
+
+
+def training_side(cfg, C, device, B=8, seed=5151):
+    """The kernels a training step adds behind the forward path, alone on an idle chip at the
+    per-GPU batch of the training configuration (8 images): RoI forward with the winner index,
+    RoI backward (255.6 MB algorithmic per image: pooled gradient + winner read, feature-map
+    gradient written) and the head's first dense layer on the pooled tensor (float32 MFMA)."""
+    from objectdetection_amd import ops
+    from objectdetection_amd.pipeline import RegionProposalPath
+    fmap, score, coord, _, _ = make_inputs(cfg, B, C, device, seed=seed)
+    path = RegionProposalPath(cfg, B, C, device, train=False, want_winner=True, depth=1)
+    path.run(fmap, score, coord)
+    fwd_ms = timed_alone(lambda: ops.roi_crop_pool_fwd(fmap, path.proposed, cfg.crop, cfg.pool,
+                                                       out=path.pooled, winner=path.winner,
+                                                       workspace=path.roi_ws), device, reps=12, skip=4)
+    dY = torch.randn_like(path.pooled)
+    dF = torch.empty_like(fmap)
+    bwd_ms = timed_alone(lambda: ops.roi_crop_pool_bwd(dY, path.winner, path.proposed, tuple(fmap.shape),
+                                                       cfg.crop, cfg.pool, out=dF), device, reps=8, skip=2)
+    bwd_bytes = dY.numel() * 4 + path.winner.numel() + dF.numel() * 4
+    del dY
+    units = 4096
+    Kf = path.pooled[0, 0].numel()
+    w = torch.randn((Kf, units), device=device) * 0.01
+    bias = torch.randn((units,), device=device)
+    out = torch.empty((B * cfg.post_n, units), device=device)
+    fc_ms = timed_alone(lambda: ops.fc1_fwd(path.pooled, w, bias, True, out=out), device, reps=6, skip=2)
+    flops = 2.0 * B * cfg.post_n * Kf * units
+    return dict(images=B,
+                roi_fwd_with_winner_ms=fwd_ms,
+                roi_bwd=dict(kernel="roi_bwd_patch_kernel", ms=bwd_ms, bytes=int(bwd_bytes), bound="hbm",
+                             achieved=bwd_bytes / (bwd_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                             frac=bwd_bytes / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             note="vector-ALU bound by the defined summation (profiles/r03_pmc_roi_bwd.txt)"),
+                fc1=dict(kernel="fc1_fwd_kernel", shape=[B * cfg.post_n, Kf, units], ms=fc_ms, bound="mfma",
+                         achieved=flops / (fc_ms * 1e-3) / 1e12, peak=F32_MFMA_PEAK_TFLOPS,
+                         unit="TFLOP/s", frac=flops / (fc_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                         dtype="f32"),
+                note="alone on an idle chip, outside the timed region; not part of `value`")
 
 
 def reference_api_step(cfg, B, C, device, fmap, score, coord, gt, label, anchor, steps, warmup):
@@ -650,6 +690,7 @@ def main():
             del path
             torch.cuda.empty_cache()
             out["single_image"] = single_image(cfg, C, device)
+            out["training_side"] = training_side(cfg, C, device)
             out["secondary"] = secondary_workload("ship768", C, device, args.steps, args.warmup, rank)
         print(json.dumps(out), flush=True)
     if dist is not None:

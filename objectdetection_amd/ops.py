@@ -333,13 +333,19 @@ def roi_fwd_prepare(rois: torch.Tensor, fmap_shape: Tuple[int, int, int, int],
 
 def roi_crop_pool_bwd(dY: torch.Tensor, winner: Optional[torch.Tensor], rois: torch.Tensor,
                       fmap_shape: Tuple[int, int, int, int], crop: Tuple[int, int] = (14, 14),
-                      pool: int = 2) -> torch.Tensor:
+                      pool: int = 2, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dY [B,R,ph,pw,C], winner u8 of the same shape (pool 2), rois [B,R,4] -> the gradient of
+    the feature map [B,H,W,C] (written in full; `out`: a contiguous float32 tensor to write into)."""
     g = _cont(dY, "dY", torch.float32)
     r = _cont(rois, "rois", torch.float32)
     w = _cont(winner, "winner", torch.uint8) if winner is not None else None
     B, H, W, Cc = fmap_shape
     R = r.shape[1]
-    out = torch.empty((B, H, W, Cc), dtype=torch.float32, device=g.device)
+    if out is None:
+        out = torch.empty((B, H, W, Cc), dtype=torch.float32, device=g.device)
+    elif (out.dtype != torch.float32 or tuple(out.shape) != (B, H, W, Cc) or not out.is_contiguous()
+          or out.device != g.device):
+        raise ValueError("out must be a contiguous float32 [B,H,W,C] tensor on dY's device")
     with torch.cuda.device(g.device):
         check("frcnn_roi_crop_pool_bwd", lib.frcnn_roi_crop_pool_bwd(
             _ptr(g), _ptr(w), _ptr(r), B, R, H, W, Cc, crop[0], crop[1], pool, _ptr(out),
