@@ -1,6 +1,6 @@
 """Time stamps of frcnn_nms_fused (FRCNN_HIP_LIB = an FRCNN_NF_TRACE build), B = 1."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import bench
 from objectdetection_amd import ops
