@@ -67,6 +67,8 @@ const char* frcnn_status_string(int status);
  *   "bwd_band"          FRCNN_BWD_BAND          patch-owner RoI backward (pool 2, crops up to
  *                                               16 x 16): 0 never (the gather kernel runs instead)
  *   "nms_fused_max_b"   FRCNN_NMS_FUSED_MAX_B   single-launch NMS for batches up to n images
+ *   "roi_band_split"    FRCNN_ROI_BAND_SPLIT    band-resident RoI forward: ranges an image's RoIs are
+ *                                               split into (<= 0: by launch size)
  * A variable present in the environment when the library is loaded gives the initial value;
  * frcnn_set_tuning replaces it (FRCNN_TUNING_UNSET restores the built-in choice).  Returns
  * FRCNN_E_BADARG for an unknown key. */

@@ -31,6 +31,7 @@ const TuneName kTune[frcnn::TUNE_COUNT] = {
     {"bwd_chunk", "FRCNN_BWD_CHUNK"},
     {"bwd_band", "FRCNN_BWD_BAND"},
     {"nms_fused_max_b", "FRCNN_NMS_FUSED_MAX_B"},
+    {"roi_band_split", "FRCNN_ROI_BAND_SPLIT"},
 };
 std::atomic<long long> g_tune[frcnn::TUNE_COUNT];
 struct TuneInit {

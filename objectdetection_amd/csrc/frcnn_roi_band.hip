@@ -313,8 +313,8 @@ template <int POOL, bool WIN>
 __global__ void __launch_bounds__(64 * BD_WAVES) __attribute__((amdgpu_waves_per_eu(5, 5)))
 roi_fwd_band_kernel(const float* __restrict__ fmap, int H, int W, int C, long long sb, long long sh,
                     long long sw, const RoiDesc* __restrict__ desc, int R, int ch, int cw,
-                    int ngroup, int nband, int nimg, int S, int T, float* __restrict__ out,
-                    uint8_t* __restrict__ winner, uint32_t key) {
+                    int ngroup, int nband, int nimg, int S, int T, int rsplit,
+                    float* __restrict__ out, uint8_t* __restrict__ winner, uint32_t key) {
     extern __shared__ __attribute__((aligned(16))) unsigned char band_lds[];
     {
         // the descriptors must be those of a call with these very dimensions (uniform: a scalar load)
@@ -324,9 +324,13 @@ roi_fwd_band_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
     // Workgroup n runs on XCD n % 8 (each XCD has its own L2).  The ngroup channel groups of one
     // (image, band) are given to one XCD at consecutive times: that L2 then sees all the 128-byte
     // pieces of an output bin (and of a descriptor) instead of an eighth of them.
-    int g, k, b;
+    // With few images the RoIs of an image are split into ranges of `rsplit` (a multiple of the
+    // claim size): workgroup (image, band, group, range), each loading the band for its share.
+    int g, k, b, split;
     {
-        const int n = (int)blockIdx.x, J = nimg * nband, full = J & ~7;
+        const int J = nimg * nband, full = J & ~7;
+        split = (int)blockIdx.x / (J * ngroup);
+        const int n = (int)blockIdx.x - split * (J * ngroup);
         int j;
         if (n < full * ngroup) { j = 8 * ((n >> 3) / ngroup) + (n & 7); g = (n >> 3) % ngroup; }
         else { const int m = n - full * ngroup; j = full + m / ngroup; g = m % ngroup; }
@@ -360,7 +364,8 @@ roi_fwd_band_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
         }
     }
     uint32_t* claim_ctr = reinterpret_cast<uint32_t*>(band_lds + (size_t)T * rowpitch + BD_LDS_RING);
-    if (threadIdx.x == 0) *claim_ctr = 0u;
+    const int r_first = split * rsplit, r_end = min(R, r_first + rsplit);
+    if (threadIdx.x == 0) *claim_ctr = (uint32_t)r_first;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 3, quad = lane & 7;
@@ -422,7 +427,7 @@ roi_fwd_band_kernel(const float* __restrict__ fmap, int H, int W, int C, long lo
     for (int i = 0; i < 8; ++i) stg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     int n_cur = claim();
 #pragma unroll 1
-    while (n_cur < R) {
+    while (n_cur < r_end) {
         uint64_t mine[BD_PIECES], mine_direct[BD_PIECES];
         fetch(n_cur, mine, mine_direct);
         const int n_base = n_cur;
@@ -664,19 +669,47 @@ extern "C" size_t frcnn_roi_fwd_workspace_bytes(int B, int R) {
 // The band kernel wins once its workgroups (B * C/32 * bands, one per CU at a time) fill the
 // chip about three times over: on the 600x1000 workload (C = 512, R = 2000, 3 bands) it takes
 // 0.66 / 1.79 / 3.38 ms at B = 16 / 32 / 64 against 1.02 / 1.94 / 3.92 ms for the per-RoI
-// kernel, and loses below (0.54 vs 0.51 ms at B = 8).  A band is loaded once per workgroup
-// whatever R is: below about a thousand RoIs per image the per-RoI kernel is the faster one.
+// kernel.  Below that size the RoIs of an image are split into ranges (band_split), which
+// brings the band kernel in front from four images on (B = 8: 0.43 against 0.50 ms).  A band
+// is loaded once per workgroup whatever R is: below about a thousand RoIs per image the per-RoI
+// kernel is the faster one.
 // FRCNN_ROI_BAND_MIN_WG = n replaces the first threshold and lifts the second (n < 0: never).
+// RoI ranges per (image, band, group): with few images the band workgroups alone do not fill the
+// chip, so each takes a share of the image's RoIs (at least BD_SPLIT_MIN_ROIS, so that loading the
+// band once per workgroup stays small against serving them)
+constexpr long long BD_BAND_MIN_WG = 768;
+constexpr int BD_SPLIT_MIN_ROIS = 256;
+static int band_split(long long base_wg, int R) {
+    // as many ranges as bring the launch to the size from which the band kernel wins: measured on
+    // the 600x1000 workload (3 bands, C = 512), per-RoI kernel / band kernel at its best split:
+    // B = 8: 504 / 425 us (2 ranges), B = 4: 268 / 250 us (5), B = 2: 149 / 145, B = 1: 88 / 86
+    // (a workgroup's fixed cost, loading its band, is ~45 us: no gain below four images)
+    long long n = base_wg > 0 ? (BD_BAND_MIN_WG + base_wg - 1) / base_wg : 1;
+    long long most = R / BD_SPLIT_MIN_ROIS;
+    if (const long long t = tuning(TUNE_ROI_BAND_SPLIT); t != TUNE_UNSET && t > 0) {
+        n = t;                                              // forced: down to one claim per range
+        most = (R + BD_RING - 1) / BD_RING;
+    }
+    if (n > most) n = most;
+    return n < 1 ? 1 : (int)n;
+}
+// RoIs per range: a multiple of the claim size
+static int band_rsplit(int R, int nsplit) {
+    const int per = (R + nsplit - 1) / nsplit;
+    return (per + BD_RING - 1) / BD_RING * BD_RING;
+}
+
 static bool band_wanted(int B, int H, int W, int C, int R, int crop_h, int crop_w, int pool,
                         bool want_winner) {
     if (C % BD_CG || (pool != 1 && pool != 2) || crop_h % pool || crop_w % pool) return false;
     const BandPlan plan = band_plan(H, W, crop_h, pool);
-    long long min_wg = 768;
+    long long min_wg = BD_BAND_MIN_WG;
     int min_roi = 1024;
     if (const long long t = tuning(TUNE_ROI_BAND_MIN_WG); t != TUNE_UNSET) { min_wg = t; min_roi = 1; }
+    const long long base_wg = (long long)B * (C / BD_CG) * plan.nb;
     return plan.ok && plan.nb < (int)BD_NONE && crop_h <= BD_MAXCROP && crop_w <= BD_MAXCROP && H < 4096 && W < 4096 &&
-           min_wg >= 0 && (long long)B * (C / BD_CG) * plan.nb >= min_wg &&
-           (long long)B * (C / BD_CG) * plan.nb <= 0x7FFFFFFFll && R >= min_roi &&
+           min_wg >= 0 && base_wg * band_split(base_wg, R) >= min_wg &&
+           base_wg * band_split(base_wg, R) <= 0x7FFFFFFFll && R >= min_roi &&
            !(pool == 1 && want_winner);
 }
 
@@ -769,7 +802,8 @@ static int roi_fwd_ws_impl(const float* fmap, int B, int H, int W, int C, int64_
         if (rc != FRCNN_OK) return rc;
     }
     const size_t lds = (size_t)plan.T * W * BD_CELL + BD_LDS_RING + 64;    // + the claim counter
-    const dim3 grid((unsigned)((long long)ngroup * plan.nb * B)), block(64 * BD_WAVES);
+    const int nsplit = band_split((long long)ngroup * plan.nb * B, R), rsplit = band_rsplit(R, nsplit);
+    const dim3 grid((unsigned)((long long)ngroup * plan.nb * B * nsplit)), block(64 * BD_WAVES);
     const uint32_t key = band_key(B, R, H, W, crop_h, crop_w, pool, plan.nb, plan.S, plan.T);
 #define FRCNN_BAND(P, WN)                                                                          \
     do {                                                                                           \
@@ -778,7 +812,7 @@ static int roi_fwd_ws_impl(const float* fmap, int B, int H, int W, int C, int64_
             return FRCNN_E_LAUNCH;                                                                 \
         FRCNN_LAUNCH((roi_fwd_band_kernel<P, WN>), grid, block, lds, st, fmap, H, W, C,            \
                      (long long)sb, (long long)sh, (long long)sw, desc, R, crop_h, crop_w, ngroup, plan.nb, B, \
-                     plan.S, plan.T, out, winner, key);                                            \
+                     plan.S, plan.T, rsplit, out, winner, key);                                    \
     } while (0)
     if (pool == 2) { if (winner) FRCNN_BAND(2, true); else FRCNN_BAND(2, false); }
     else           { FRCNN_BAND(1, false); }

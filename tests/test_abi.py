@@ -88,13 +88,17 @@ def test_no_entry_point_reads_the_environment():
 def test_roi_forward_plan_and_prepare_argument_checks():
     """Which RoI forward kernel a call gets is host logic (no launch): the band-resident kernel
     from 768 workgroups (B * C/32 * bands) and 1,024 RoIs per image on, the per-RoI one below;
-    the tuning value roi_band_min_wg moves the threshold."""
+    the tuning value roi_band_min_wg moves the threshold.  Between 4 and 15 images the RoIs of an
+    image are split into ranges so that the band kernel's launch still reaches that size."""
     from objectdetection_amd import _lib, ops
     L = _lib.lib
     _lib.set_tuning("roi_band_min_wg", None)
     assert L.frcnn_roi_fwd_plan(64, 37, 62, 512, 2000, 14, 14, 2, 0) == 1      # 64 x 16 x 3 bands
     assert L.frcnn_roi_fwd_plan(16, 37, 62, 512, 2000, 14, 14, 2, 1) == 1      # 768 workgroups
-    assert L.frcnn_roi_fwd_plan(15, 37, 62, 512, 2000, 14, 14, 2, 0) == 0
+    assert L.frcnn_roi_fwd_plan(15, 37, 62, 512, 2000, 14, 14, 2, 0) == 1      # 720 x 2 ranges of RoIs
+    assert L.frcnn_roi_fwd_plan(4, 37, 62, 512, 2000, 14, 14, 2, 0) == 1       # 192 x 4 ranges
+    assert L.frcnn_roi_fwd_plan(2, 37, 62, 512, 2000, 14, 14, 2, 0) == 0       # 96 x 7 (>= 256 RoIs each)
+    assert L.frcnn_roi_fwd_plan(1, 37, 62, 512, 2000, 14, 14, 2, 0) == 0
     assert L.frcnn_roi_fwd_plan(64, 37, 62, 512, 1000, 14, 14, 2, 0) == 0      # few RoIs per image
     assert L.frcnn_roi_fwd_plan(64, 37, 62, 500, 2000, 14, 14, 2, 0) == 0      # C % 32
     assert L.frcnn_roi_fwd_plan(64, 37, 62, 512, 2000, 18, 18, 2, 0) == 0      # crop > 16
@@ -102,7 +106,8 @@ def test_roi_forward_plan_and_prepare_argument_checks():
     assert L.frcnn_roi_fwd_plan(16, 48, 48, 512, 1500, 14, 14, 2, 0) == 1      # the ship workload
     assert L.frcnn_roi_fwd_plan(0, 37, 62, 512, 2000, 14, 14, 2, 0) == 0
     assert ops.roi_fwd_kernel_name(64, 37, 62, 512, 2000, (14, 14), 2) == "roi_fwd_band_kernel<2,false>"
-    assert ops.roi_fwd_kernel_name(8, 37, 62, 512, 2000, (14, 14), 2, True) == "roi_fwd_stage_kernel<2,true>"
+    assert ops.roi_fwd_kernel_name(8, 37, 62, 512, 2000, (14, 14), 2, True) == "roi_fwd_band_kernel<2,true>"
+    assert ops.roi_fwd_kernel_name(2, 37, 62, 512, 2000, (14, 14), 2, True) == "roi_fwd_stage_kernel<2,true>"
     _lib.set_tuning("roi_band_min_wg", 1)
     assert L.frcnn_roi_fwd_plan(1, 9, 11, 64, 30, 14, 14, 2, 0) == 1
     _lib.set_tuning("roi_band_min_wg", -1)
@@ -113,7 +118,7 @@ def test_roi_forward_plan_and_prepare_argument_checks():
     assert L.frcnn_roi_fwd_workspace_bytes(64, 2000) == (64 * 2000 * 272 + 16 + 255) // 256 * 256
     assert L.frcnn_roi_fwd_prepare(None, 64, 37, 62, 512, 2000, 14, 14, 2, 0, one, 1 << 30, None) == _lib.E_BADARG
     # nothing to prepare: small call, missing or short workspace (no launch in any of these)
-    assert L.frcnn_roi_fwd_prepare(one, 8, 37, 62, 512, 2000, 14, 14, 2, 0, one, 1 << 30, None) == 0
+    assert L.frcnn_roi_fwd_prepare(one, 2, 37, 62, 512, 2000, 14, 14, 2, 0, one, 1 << 30, None) == 0
     assert L.frcnn_roi_fwd_prepare(one, 64, 37, 62, 512, 2000, 14, 14, 2, 0, None, 0, None) == 0
     assert L.frcnn_roi_fwd_prepare(one, 64, 37, 62, 512, 2000, 14, 14, 2, 0, one, 1000, None) == 0
 

@@ -74,13 +74,16 @@ class _Path:
                                      workspace=ws, prepared=prepared)
 
 
-@pytest.fixture(params=["per_roi", "band", "band_prepared", "planar"])
+@pytest.fixture(params=["per_roi", "band", "band_prepared", "band_split", "planar"])
 def ws_for(request, tuning):
     """The forward entry points: frcnn_roi_crop_pool_fwd (one wave per RoI and slice),
     frcnn_roi_crop_pool_fwd_ws with its band kernel forced on at test sizes, and the same entry
     point on a planar [B,C,H,W] map (transposed into the workspace, then the per-RoI kernel)."""
-    if request.param in ("band", "band_prepared"):     # the two-call form: prepare, then run
+    if request.param in ("band", "band_prepared", "band_split"):   # band_prepared: prepare, then run
         tuning("roi_band_min_wg", 1)
+    if request.param == "band_split":                  # an image's RoIs in 7 ranges of workgroups
+        tuning("roi_band_split", 7)
+        return _Path("band")
     return _Path(request.param)
 
 
