@@ -7,7 +7,7 @@
 // Reference: Faster_RCNN/module/model.py:45-48 (= module/data.py:203-206).
 //
 // Four passes over 8-bit digits of the ascending key desc_key(score); per pass
-//   hist    : per 1024-element block, digit histogram                         [B][nblk][256]
+//   hist    : per 1024-element block, digit histogram (one LDS atomic per element) [B][nblk][256]
 //   scatter : every block first derives the output place of its first element of every digit
 //             from the image's histograms (exclusive scan over (digit, block): a few hundred
 //             instructions per block, cheaper than a launch of its own between the two
@@ -73,13 +73,21 @@ ts_hist_kernel(const float* __restrict__ scores, const uint32_t* __restrict__ ke
         const int i = blk * TS_BLK + it * 64 + lane;
         const bool valid = i < N;
         const uint32_t dg = valid ? (ts_key<PASS>(scores, keys_in, base + i) >> (8 * PASS)) & 255u : 0u;
+#ifdef FRCNN_TS_HIST_BALLOT
         const unsigned long long peers = same_digit(dg, valid);
         if (valid && lane == __ffsll((long long)peers) - 1) {
             volatile uint32_t* p = &h[dg];
             *p = *p + (uint32_t)__popcll(peers);
         }
         __builtin_amdgcn_wave_barrier();
+#else
+        // one LDS atomic per lane: the hardware serialises lanes that meet in a bin, which costs
+        // less than finding them with eight ballots first (the counts do not depend on the order)
+        if (valid) __hip_atomic_fetch_add(&h[dg], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
     }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): the atomics have landed
 #pragma unroll
     for (int t = 0; t < 4; ++t)
         hist[((size_t)b * nblk + blk) * 256 + t * 64 + lane] =
