@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""What a size-keyed NMS would save on the bench's boxes (CPU, oracle only; a tool, not product
+"""What a size-keyed NMS would save on the bench's boxes (CPU; it uses the oracle, hence its place under tests/: a tool, not product
 code): kept boxes sorted by a size key per 1,024-candidate run, a kept tile of 64 rows tested only
 against the columns whose key lies within one bucket (width log2(1/0.7): IoU > 0.7 needs height,
 width and area each within that factor) of the tile's key range.  Prints the share of the kept
