@@ -10,16 +10,16 @@
 //     acc = 0; for k = 0 .. K-1: acc = fmaf(x[m][k], w[k][n], acc); out = max(acc + b[n], 0)
 // which is the layer's defined summation order.  There is no split over k for that reason.
 //
-// Workgroup = 128 x 128 outputs, four waves of 64 x 64 (2 x 2 MFMA blocks, 64 accumulator
-// registers); k in steps of 32 through two LDS buffers, the next step's tiles loaded to
-// registers while the current one is multiplied.  x rows are read as full 128-byte lines (8 lanes
-// per row) and transposed on their way into LDS (As[k][m], row stride 129 floats: the four
-// transposing 4-byte stores of a lane group and the row-contiguous fragment reads are both
-// conflict-free); W rows are copied as they are.  One fragment read per operand and MFMA block:
-// 4 LDS reads per 4 MFMAs (256 cycles), issued one k pair ahead of the MFMAs that use them (the
-// four MFMAs of a pair take ~190 cycles to issue, so a read issued behind them and waited for
-// right away stalled the wave: 117 -> 125 TFLOP/s).  k steps of 16 with three or four workgroups
-// per compute unit instead of two measured the same (FRCNN_FC_BK / FRCNN_FC_WGS).
+// Workgroup = 256 x 128 outputs, four waves of 128 x 64 (4 x 2 MFMA blocks, 128 accumulator
+// registers); k in steps of 16 through two LDS buffers, the next step's tiles loaded to registers
+// while the current one is multiplied.  x rows are read as 64-byte pieces (4 lanes per row) and
+// transposed on their way into LDS (As[k][m], row stride BM + 1 floats); W rows are copied as they
+// are.  One fragment read per operand block and k pair: 6 LDS reads per 8 MFMAs (512 cycles),
+// issued one k pair ahead of the MFMAs that use them (the MFMAs of a pair take a few hundred
+// cycles to issue, so a read issued behind them and waited for right away stalled the wave:
+// 117 -> 125 TFLOP/s; the 4 x 2 wave tile instead of 2 x 2: -> 127).  Measured the same or slower:
+// three or four workgroups per compute unit, loads two k steps ahead, v_mfma_f32_16x16x4_f32
+// (bit-identical, 114 TFLOP/s).
 //
 // Workgroup n runs on XCD n % 8.  Each XCD works through 8 x 8 super-tiles of workgroup tiles
 // (the 64 workgroups resident on its 32 CUs at two per CU): inside one, every x tile and every W
@@ -32,13 +32,18 @@ typedef float fc_f32x4 __attribute__((ext_vector_type(4)));
 typedef float fc_f32x16 __attribute__((ext_vector_type(16)));
 
 #ifndef FRCNN_FC_BK
-#define FRCNN_FC_BK 32
+#define FRCNN_FC_BK 16
 #endif
 #ifndef FRCNN_FC_WGS
 #define FRCNN_FC_WGS 2
 #endif
-constexpr int FC_BM = 128, FC_BN = 128, FC_BK = FRCNN_FC_BK;
-constexpr int FC_NP = FC_BK / 8;            // 16-byte pieces of each operand tile per thread
+#ifndef FRCNN_FC_MB
+#define FRCNN_FC_MB 4
+#endif
+constexpr int FC_MB = FRCNN_FC_MB, FC_NB = 2;   // 32 x 32 MFMA blocks per wave (rows x columns)
+constexpr int FC_BM = 2 * 32 * FC_MB, FC_BN = 2 * 32 * FC_NB, FC_BK = FRCNN_FC_BK;
+constexpr int FC_NPA = FC_BM * FC_BK / 4 / 256;   // 16-byte pieces of the x tile per thread
+constexpr int FC_NPB = FC_BN * FC_BK / 4 / 256;   // ... of the W tile
 constexpr int FC_RP = FC_BK / 4;            // pieces per x row of a k step
 constexpr int FC_AS = FC_BM + 1;            // floats between k rows of the transposed x tile
 constexpr int FC_BS = FC_BN;                // floats between k rows of the W tile
@@ -71,16 +76,20 @@ fc1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
     // global -> register staging: four 16-byte pieces of each operand per thread
     // x tile: piece idx = tid + 256 i -> row idx / 8, floats 4 (idx % 8) .. +3 of the k step
     // W tile: piece idx -> k row idx / 32, floats 4 (idx % 32) .. +3
-    fc_f32x4 ra[FC_NP], rb[FC_NP];
+    fc_f32x4 ra[FC_NPA], rb[FC_NPB];
     auto load_tiles = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < FC_NP; ++i) {
+        for (int i = 0; i < FC_NPA; ++i) {
             const int idx = tid + 256 * i;
             const int am = idx / FC_RP, ak = k0 + 4 * (idx % FC_RP);
             const long long gm = m_base + am;
             ra[i] = fc_f32x4{0.f, 0.f, 0.f, 0.f};
             if (gm < M && ak < K)
                 ra[i] = *reinterpret_cast<const fc_f32x4*>(x + (size_t)gm * (size_t)K + ak);
+        }
+#pragma unroll
+        for (int i = 0; i < FC_NPB; ++i) {
+            const int idx = tid + 256 * i;
             const int bk = k0 + (idx >> 5), bn = n_base + 4 * (idx & 31);
             rb[i] = fc_f32x4{0.f, 0.f, 0.f, 0.f};
             if (bk < K && bn < N)
@@ -89,20 +98,24 @@ fc1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
     };
     auto store_tiles = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < FC_NP; ++i) {
+        for (int i = 0; i < FC_NPA; ++i) {
             const int idx = tid + 256 * i;
             const int am = idx / FC_RP, ak = 4 * (idx % FC_RP);
             float* a = &As[buf][ak * FC_AS + am];
             a[0] = ra[i].x; a[FC_AS] = ra[i].y; a[2 * FC_AS] = ra[i].z; a[3 * FC_AS] = ra[i].w;
+        }
+#pragma unroll
+        for (int i = 0; i < FC_NPB; ++i) {
+            const int idx = tid + 256 * i;
             *reinterpret_cast<fc_f32x4*>(&Bs[buf][(idx >> 5) * FC_BS + 4 * (idx & 31)]) = rb[i];
         }
     };
 
-    fc_f32x16 acc[2][2];
+    fc_f32x16 acc[FC_MB][FC_NB];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < FC_MB; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < FC_NB; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -115,25 +128,33 @@ fc1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
         if (t + 1 < nt) load_tiles((t + 1) * FC_BK);
-        const float* as = &As[buf][half * FC_AS + wm * 64 + r32];
-        const float* bs = &Bs[buf][half * FC_BS + wn * 64 + r32];
-        // fragments one k pair ahead: the reads of pair kk + 2 are issued in front of the four
-        // MFMAs of pair kk, whose issue alone takes ~190 cycles, so the wait that follows is short
-        float a0 = as[0], a1 = as[32], b0 = bs[0], b1 = bs[32];
+        const float* as = &As[buf][half * FC_AS + wm * (32 * FC_MB) + r32];
+        const float* bs = &Bs[buf][half * FC_BS + wn * (32 * FC_NB) + r32];
+        // fragments one k pair ahead: the reads of pair kk + 2 are issued in front of the MFMAs
+        // of pair kk, whose issue alone takes a few hundred cycles, so the wait that follows is short
+        float a[FC_MB], b[FC_NB];
+#pragma unroll
+        for (int i = 0; i < FC_MB; ++i) a[i] = as[32 * i];
+#pragma unroll
+        for (int j = 0; j < FC_NB; ++j) b[j] = bs[32 * j];
 #pragma unroll
         for (int kk = 0; kk < FC_BK; kk += 2) {
-            float na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
-            if (kk + 2 < FC_BK) {
-                na0 = as[(kk + 2) * FC_AS]; na1 = as[(kk + 2) * FC_AS + 32];
-                nb0 = bs[(kk + 2) * FC_BS]; nb1 = bs[(kk + 2) * FC_BS + 32];
-            }
+            float na[FC_MB], nb[FC_NB];
+#pragma unroll
+            for (int i = 0; i < FC_MB; ++i) na[i] = kk + 2 < FC_BK ? as[(kk + 2) * FC_AS + 32 * i] : a[i];
+#pragma unroll
+            for (int j = 0; j < FC_NB; ++j) nb[j] = kk + 2 < FC_BK ? bs[(kk + 2) * FC_BS + 32 * j] : b[j];
             __builtin_amdgcn_sched_barrier(0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < FC_MB; ++i)
+#pragma unroll
+                for (int j = 0; j < FC_NB; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+#pragma unroll
+            for (int i = 0; i < FC_MB; ++i) a[i] = na[i];
+#pragma unroll
+            for (int j = 0; j < FC_NB; ++j) b[j] = nb[j];
         }
         if (t + 1 < nt) store_tiles(buf ^ 1);
         __syncthreads();
@@ -141,15 +162,15 @@ fc1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
 
     // accumulator element r of a lane: column lane & 31, row (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n_base + wn * 64 + j * 32 + r32;
+    for (int j = 0; j < FC_NB; ++j) {
+        const int col = n_base + wn * (32 * FC_NB) + j * 32 + r32;
         if (col >= N) continue;
         const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < FC_MB; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const long long row = m_base + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const long long row = m_base + wm * (32 * FC_MB) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (row >= M) continue;
                 float v = acc[i][j][r];
                 if (bias) v = v + bv;
