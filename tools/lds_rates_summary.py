@@ -4,8 +4,14 @@ pass: per kernel, conflict cycles / LDS-array cycles (sums over all dispatches).
 import csv
 import glob
 import json
+import os
+import subprocess
 import sys
 from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (the hash of the kernel sources the record belongs to)
 
 root, out = sys.argv[1], sys.argv[2]
 acc = defaultdict(lambda: defaultdict(float))
@@ -22,6 +28,9 @@ for k, c in sorted(acc.items()):
                     "rate": c.get("SQ_LDS_BANK_CONFLICT", 0.0) / act}
 json.dump({"source": "rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -- python3 tools/lds_rates.py "
                      "(600x1000 workload, B = 64, training path, both top-k variants)",
+           "csrc_sha": bench.sources_sha(),
+           "commit": subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True,
+                                    text=True).stdout.strip(),
            "rates": rates}, open(out, "w"), indent=1)
 for k, v in rates.items():
     print(f"{v['rate']:.4f}  {k}")
