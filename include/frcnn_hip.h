@@ -69,6 +69,10 @@ const char* frcnn_status_string(int status);
  *   "nms_fused_max_b"   FRCNN_NMS_FUSED_MAX_B   single-launch NMS for batches up to n images
  *   "roi_band_split"    FRCNN_ROI_BAND_SPLIT    band-resident RoI forward: ranges an image's RoIs are
  *                                               split into (<= 0: by launch size)
+ *   "topk_merge_max_runs" FRCNN_TOPK_MERGE_MAX_RUNS frcnn_topk_sort: calls of up to n blocks of 1,024
+ *                                               scores (all images together) sort each block in one
+ *                                               wave and rank across blocks, two launches instead
+ *                                               of the radix passes' eight (0: never)
  * A variable present in the environment when the library is loaded gives the initial value;
  * frcnn_set_tuning replaces it (FRCNN_TUNING_UNSET restores the built-in choice).  Returns
  * FRCNN_E_BADARG for an unknown key. */
@@ -150,8 +154,11 @@ int frcnn_topk(const float* scores, int B, int N, int K,
 
 /* The same result by a stable radix sort through global memory, from small workgroups: any
  * 1 <= K <= N, and it shares the chip with a concurrent bandwidth-bound kernel (frcnn_topk's
- * workgroups need a CU to themselves).  workspace: frcnn_topk_sort_workspace_bytes(B,N)
- * bytes (about 16 bytes per score), 256-byte aligned. */
+ * workgroups need a CU to themselves).  A call of a few images (tuning value
+ * "topk_merge_max_runs") takes two launches instead: one wave sorts each block of 1,024
+ * scores, then every score's place is its place in its block plus the smaller scores of all
+ * other blocks of its image.  workspace: frcnn_topk_sort_workspace_bytes(B,N) bytes (about
+ * 16 bytes per score), 256-byte aligned. */
 size_t frcnn_topk_sort_workspace_bytes(int B, int N);
 int frcnn_topk_sort(const float* scores, int B, int N, int K,
                     const float* anchors, const float* deltas,

@@ -32,6 +32,7 @@ const TuneName kTune[frcnn::TUNE_COUNT] = {
     {"bwd_band", "FRCNN_BWD_BAND"},
     {"nms_fused_max_b", "FRCNN_NMS_FUSED_MAX_B"},
     {"roi_band_split", "FRCNN_ROI_BAND_SPLIT"},
+    {"topk_merge_max_runs", "FRCNN_TOPK_MERGE_MAX_RUNS"},
 };
 std::atomic<long long> g_tune[frcnn::TUNE_COUNT];
 struct TuneInit {

@@ -39,6 +39,8 @@ enum Tuning {
     TUNE_BWD_BAND,            // FRCNN_BWD_BAND: patch-owner backward (0: off, the gather kernel runs; else on)
     TUNE_NMS_FUSED_MAX_B,     // FRCNN_NMS_FUSED_MAX_B: one-launch NMS up to this many images
     TUNE_ROI_BAND_SPLIT,      // FRCNN_ROI_BAND_SPLIT: RoI ranges per band workgroup set (0 = by size)
+    TUNE_TOPK_MERGE_MAX_RUNS, // FRCNN_TOPK_MERGE_MAX_RUNS: sorted-runs top-k up to this many 1,024-score blocks
+                              // in the call (0: never, the radix sort runs)
     TUNE_COUNT
 };
 constexpr long long TUNE_UNSET = (long long)0x8000000000000000ull;

@@ -501,8 +501,9 @@ __device__ __forceinline__ int nf_wait(const int* p, int want, int* abort_word) 
     return -1;
 }
 
-__global__ void nms_fused_init_kernel(int* words, int n) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) words[i] = 0;
+__global__ void nms_fused_init_kernel(int* words, int n, int* more, int m) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) words[i] = 0;
+    for (int i = threadIdx.x; i < m; i += blockDim.x) more[i] = 0;
 }
 
 // tile t = (row block ibl of chunk s-1, column block jbl of chunk s): a full 64 x 64 tile
@@ -942,12 +943,9 @@ extern "C" int frcnn_nms_fused(const float* boxes, int B, int K, float iou_thres
     NW = NW > 256 - B ? 256 - B : NW;
     // the counters and the kept words start from zero (one small launch; nothing else is read
     // before it is written)
-    const int nzero = (int)(nf_ints(B, K) + (size_t)B * 2 * NMS_CW * 2);
     static_assert(sizeof(unsigned long long) == 8, "deadK words are zeroed as pairs of ints");
-    FRCNN_LAUNCH(nms_fused_init_kernel, dim3(1), dim3(1024), 0, st, ints, (int)nf_ints(B, K));
-    FRCNN_LAUNCH(nms_fused_init_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<int*>(ws.deadK),
-                 B * 2 * NMS_CW * 2);
-    (void)nzero;
+    FRCNN_LAUNCH(nms_fused_init_kernel, dim3(1), dim3(1024), 0, st, ints, (int)nf_ints(B, K),
+                 reinterpret_cast<int*>(ws.deadK), B * 2 * NMS_CW * 2);
     FRCNN_LAUNCH(nms_fused_kernel, dim3(B + NW), dim3(NF_THREADS), 0, st,
                  reinterpret_cast<const float4*>(boxes), B, K, post_n, nchunk, NW, iou_threshold,
                  1.0f + iou_threshold, iou_threshold * 0.999996f, ws,

@@ -1283,7 +1283,10 @@ extern "C" int frcnn_roi_crop_pool_fwd(const float* fmap, int B, int H, int W, i
                            (long long)(crop_h / pool) * (crop_w / pool) * C * 4 < 0x7FFFFFFFll;
     if (walk_path) {
         const int nslice = C / RW_CS;
-        const int nsub = FRCNN_ST_NSUB <= nslice && nslice % FRCNN_ST_NSUB == 0 ? FRCNN_ST_NSUB : 1;
+        // a wave walks FRCNN_ST_NSUB slices of a RoI in turn (its geometry is worked out once),
+        // unless one slice per wave is what it takes to give every SIMD a few waves
+        const bool few = (long long)R * B * nslice <= 16384;
+        const int nsub = !few && FRCNN_ST_NSUB <= nslice && nslice % FRCNN_ST_NSUB == 0 ? FRCNN_ST_NSUB : 1;
         const int ngrp = nslice / nsub;
         const dim3 g3((unsigned)(R * ngrp), B), b3(64);
 #define FRCNN_WALK(P, WN)                                                                       \

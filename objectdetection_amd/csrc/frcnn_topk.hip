@@ -13,8 +13,12 @@
 //             instructions per block, cheaper than a launch of its own between the two
 //             kernels while another stream's kernel fills the chip), then every element
 //             goes to that place + its rank among the block's elements of that digit (rank in
-//             element order = stable)
-// and a final gather of the first K: nine launches.  gfx950, wave64.
+//             element order = stable).  The last scatter writes the first K places straight
+//             into the outputs (score, index, decoded box) and drops the rest.
+// Eight launches.  (Counting an element into the NEXT pass's histogram from the scatter, by a
+// global atomic at its new place, removes three launches and was slower: 97 us against 86 for
+// one image, 207 against 132 for 64 -- one memory-side atomic per element and pass.)
+// gfx950, wave64.
 #include "frcnn_common.h"
 
 namespace frcnn {
@@ -94,12 +98,22 @@ ts_hist_kernel(const float* __restrict__ scores, const uint32_t* __restrict__ ke
             *(volatile uint32_t*)&h[t * 64 + lane];
 }
 
+// The first K places of the last pass, written where the caller wants them.
+struct TsOut {
+    int K;
+    const float4* anchors;
+    const float4* deltas;
+    float* top_scores;
+    int32_t* top_idx;
+    float4* cand;
+};
+
 template <int PASS>
 __global__ void __launch_bounds__(64)
 ts_scatter_kernel(const float* __restrict__ scores, const uint32_t* __restrict__ keys_in,
                   const int32_t* __restrict__ idx_in, int N, int nblk, int B,
                   const uint32_t* __restrict__ hist, uint32_t* __restrict__ keys_out,
-                  int32_t* __restrict__ idx_out) {
+                  int32_t* __restrict__ idx_out, TsOut out) {
     __shared__ __attribute__((aligned(16))) uint32_t nextpos[256];   // next output place of each digit
     const int lane = threadIdx.x;
     int blk, b;
@@ -158,24 +172,282 @@ ts_scatter_kernel(const float* __restrict__ scores, const uint32_t* __restrict__
             }
             first = __shfl(first, leader);
             const uint32_t pos = first + (uint32_t)__popcll(peers & lanemask_lt());
-            keys_out[base + pos] = key[it];
-            idx_out[base + pos] = src[it];
+            if (PASS < 3) {
+                keys_out[base + pos] = key[it];
+                idx_out[base + pos] = src[it];
+            } else if ((int)pos < out.K) {
+                const size_t o = (size_t)b * out.K + pos;
+                out.top_idx[o] = src[it];
+                out.top_scores[o] = scores[base + src[it]];
+                if (out.cand)
+                    out.cand[o] = decode_box(out.anchors[src[it]], out.deltas[base + src[it]], false);
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
 }
 
-__global__ void __launch_bounds__(64)
-ts_gather_kernel(const float* __restrict__ scores, const int32_t* __restrict__ idx_sorted, int N,
-                 int K, const float4* __restrict__ anchors, const float4* __restrict__ deltas,
-                 float* __restrict__ top_scores, int32_t* __restrict__ top_idx,
-                 float4* __restrict__ cand) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
-    if (r >= K) return;
-    const int i = idx_sorted[(size_t)b * N + r];
-    top_idx[(size_t)b * K + r] = i;
-    top_scores[(size_t)b * K + r] = scores[(size_t)b * N + i];
-    if (cand) cand[(size_t)b * K + r] = decode_box(anchors[i], deltas[(size_t)b * N + i], false);
+// ---- few images: sorted runs + ranks ----------------------------------------------------------
+// The radix passes above are eight dependent launches of a few microseconds each: for one image
+// that chain IS the cost.  When the whole call is a few hundred blocks, two launches do it:
+//   runs : every 1,024-element block is sorted by one 256-thread workgroup (bitonic network, four
+//          elements per thread; element = key << 32 | index, so every element is distinct and
+//          the order of equal scores is the index order the radix sort keeps); keys and indices
+//          are stored apart
+//   rank : an element's place in the image = its place in its own run + the number of elements
+//          of every other run that come before it.  A run holds consecutive indices, so among
+//          equal keys a whole earlier run comes before and a whole later run after: the count is
+//          a binary search on the 32-bit keys alone (<= for earlier runs, < for later ones).
+//          The other runs of a run are shared out over `nsplit` workgroups and their waves
+//          (one or two runs per wave, staged through LDS, the sixteen elements of a lane
+//          searched in step so that sixteen LDS reads are in flight); a workgroup leaves its
+//          partial counts in memory, and the one that arrives last adds them up and writes the
+//          first K places straight into the outputs.
+// Same result, bit for bit.  Work grows with runs-per-image squared, so the radix sort stays
+// the path for batches.
+constexpr int TM_RUN = 1024;
+constexpr int TM_THREADS = 256;
+constexpr int TM_WAVES = TM_THREADS / 64;
+constexpr int TM_PER_THREAD = TM_RUN / TM_THREADS;      // 4
+constexpr int TM_PER_LANE = TM_RUN / 64;                // 16: a wave of the rank kernel holds the run
+constexpr int TM_MAX_RUNS_PER_IMAGE = 64;
+constexpr int TM_MAX_SPLIT = 8;
+constexpr long long TM_DEFAULT_MAX_RUNS = 256;           // blocks in the call (images x blocks)
+
+struct TmWorkspace {
+    uint32_t* keys;      // [B][nblk][TM_RUN] sorted keys of every run
+    int32_t* idx;        // [B][nblk][TM_RUN] their score indices
+    uint32_t* part;      // [B][nblk][nsplit][TM_RUN] partial counts
+    int* arrived;        // [B][nblk] workgroups of the run that have left their counts
+};
+
+__device__ __forceinline__ unsigned long long tm_xor_lane(unsigned long long v, int mask) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, mask);
+    const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), mask);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// ascending bitonic sort of TM_RUN elements by TM_THREADS threads; element e sits in thread
+// e / TM_PER_THREAD, register e % TM_PER_THREAD.  Partners in the same wave are exchanged by
+// lane permutes, partners in another wave through `s` (TM_RUN words).
+__device__ __forceinline__ void tm_sort_block(unsigned long long (&v)[TM_PER_THREAD], int tid,
+                                              unsigned long long* s) {
+    constexpr int T = TM_PER_THREAD;
+#pragma unroll
+    for (int k = 2; k <= TM_RUN; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j >= 1; j >>= 1) {
+            if (j >= T) {                               // partner: same register, thread tid ^ (j / T)
+                const int tj = j / T;
+                const bool asc = ((tid * T) & k) == 0;
+                const bool keep_min = ((tid & tj) == 0) == asc;
+                unsigned long long o[T];
+                if (tj < 64) {
+#pragma unroll
+                    for (int it = 0; it < T; ++it) o[it] = tm_xor_lane(v[it], tj);
+                } else {
+                    __syncthreads();                    // the words of the exchange before are read
+#pragma unroll
+                    for (int it = 0; it < T; ++it) s[tid * T + it] = v[it];
+                    __syncthreads();
+#pragma unroll
+                    for (int it = 0; it < T; ++it) o[it] = s[(tid ^ tj) * T + it];
+                }
+#pragma unroll
+                for (int it = 0; it < T; ++it) {
+                    const bool take = keep_min ? o[it] < v[it] : o[it] > v[it];
+                    v[it] = take ? o[it] : v[it];
+                }
+            } else {                                    // partner: register it ^ j of this thread
+#pragma unroll
+                for (int it = 0; it < T; ++it) {
+                    if ((it & j) != 0) continue;
+                    const int p = it | j;
+                    const bool asc = (((tid * T) | it) & k) == 0;
+                    const unsigned long long a = v[it], c = v[p];
+                    const bool sw = asc ? a > c : a < c;
+                    v[it] = sw ? c : a;
+                    v[p] = sw ? a : c;
+                }
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(TM_THREADS)
+tm_runs_kernel(const float* __restrict__ scores, int N, int nblk, TmWorkspace ws) {
+    __shared__ unsigned long long s[TM_RUN];
+    const int tid = threadIdx.x, blk = blockIdx.x, b = blockIdx.y;
+    const size_t base = (size_t)b * N;
+    unsigned long long v[TM_PER_THREAD];
+#pragma unroll
+    for (int it = 0; it < TM_PER_THREAD; ++it) {
+        const int i = blk * TM_RUN + it * TM_THREADS + tid;     // coalesced; any start order will do
+        v[it] = i < N ? ((unsigned long long)desc_key(scores[base + i]) << 32) | (uint32_t)i
+                      : ~0ull;                          // filler: behind every element
+    }
+    tm_sort_block(v, tid, s);
+    const size_t run = (size_t)b * nblk + blk;
+    uint4 k4, i4;
+    k4.x = (uint32_t)(v[0] >> 32); k4.y = (uint32_t)(v[1] >> 32);
+    k4.z = (uint32_t)(v[2] >> 32); k4.w = (uint32_t)(v[3] >> 32);
+    i4.x = (uint32_t)v[0]; i4.y = (uint32_t)v[1]; i4.z = (uint32_t)v[2]; i4.w = (uint32_t)v[3];
+    static_assert(TM_PER_THREAD == 4, "a thread stores its four keys as one 16-byte word");
+    reinterpret_cast<uint4*>(ws.keys + run * TM_RUN)[tid] = k4;
+    reinterpret_cast<uint4*>(ws.idx + run * TM_RUN)[tid] = i4;
+    if (tid == 0) ws.arrived[run] = 0;
+}
+
+// For the sixteen keys of a lane: how many of the sorted keys s[0 .. TM_RUN) come before each.
+// TIES: equal keys of s come before (s is an earlier run).
+template <bool TIES>
+__device__ __forceinline__ void tm_count(const uint32_t* s, const uint32_t (&own)[TM_PER_LANE],
+                                         uint32_t (&cnt)[TM_PER_LANE]) {
+    constexpr int L = TM_PER_LANE;
+    uint32_t pos[L];
+#pragma unroll
+    for (int it = 0; it < L; ++it) pos[it] = 0;
+#pragma unroll 1
+    for (int h = TM_RUN / 2; h >= 1; h >>= 1) {
+        uint32_t w[L];
+#pragma unroll
+        for (int it = 0; it < L; ++it) w[it] = s[pos[it] + h - 1];
+#pragma unroll
+        for (int it = 0; it < L; ++it) pos[it] += (TIES ? w[it] <= own[it] : w[it] < own[it]) ? h : 0;
+    }
+    uint32_t w[L];
+#pragma unroll
+    for (int it = 0; it < L; ++it) w[it] = s[pos[it]];
+#pragma unroll
+    for (int it = 0; it < L; ++it)
+        cnt[it] += pos[it] + ((TIES ? w[it] <= own[it] : w[it] < own[it]) ? 1u : 0u);
+}
+
+__global__ void __launch_bounds__(TM_THREADS)
+tm_rank_kernel(const float* __restrict__ scores, int N, int nblk, int nsplit, TmWorkspace ws,
+               TsOut out) {
+    constexpr int L = TM_PER_LANE;
+    __shared__ __attribute__((aligned(16))) uint32_t s_run[TM_WAVES][2][TM_RUN];    // 32 KB
+    __shared__ int s_last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int blk = blockIdx.x, split = blockIdx.y, b = blockIdx.z;
+    const size_t run0 = (size_t)b * nblk;
+    const uint32_t* keys = ws.keys + run0 * TM_RUN;
+    // every wave holds the keys of the whole run, sixteen consecutive ones per lane
+    uint32_t own[L], cnt[L];
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(keys + (size_t)blk * TM_RUN + lane * L);
+#pragma unroll
+        for (int t = 0; t < L / 4; ++t) {
+            const uint4 v = src[t];
+            own[4 * t] = v.x; own[4 * t + 1] = v.y; own[4 * t + 2] = v.z; own[4 * t + 3] = v.w;
+        }
+#pragma unroll
+        for (int it = 0; it < L; ++it) cnt[it] = 0;
+    }
+    // what the outputs of elements 4 tid .. 4 tid + 3 will need, asked for now: the workgroup that
+    // arrives last writes them, and which one that is shows only at the end
+    const size_t base = (size_t)b * N;
+    int idx[TM_PER_THREAD];
+    bool live[TM_PER_THREAD];
+    float sc[TM_PER_THREAD];
+    float4 an[TM_PER_THREAD], dl[TM_PER_THREAD];
+    {
+        const uint4 i4 = reinterpret_cast<const uint4*>(ws.idx + (run0 + blk) * TM_RUN)[tid];
+        const uint32_t mine_idx[TM_PER_THREAD] = {i4.x, i4.y, i4.z, i4.w};
+#pragma unroll
+        for (int it = 0; it < TM_PER_THREAD; ++it) {
+            live[it] = mine_idx[it] != 0xFFFFFFFFu;    // a filler's index (no score has it: N < 2^31)
+            idx[it] = live[it] ? (int)mine_idx[it] : 0;
+            sc[it] = scores[base + idx[it]];
+            if (out.cand) {
+                an[it] = out.anchors[idx[it]];
+                dl[it] = out.deltas[base + idx[it]];
+            }
+        }
+    }
+    // this wave's share of the other runs: every (TM_WAVES * nsplit)-th of the runs that are not
+    // blk.  The next one is on its way from memory while this one is searched.
+    const int stride = TM_WAVES * nsplit;
+    static_assert(L == 16, "a lane moves a run as four 16-byte words");
+    uint4 n0, n1, n2, n3;
+    n0 = n1 = n2 = n3 = make_uint4(0, 0, 0, 0);
+    int q = split * TM_WAVES + wave;                    // position in the list of other runs
+    int r = q < blk ? q : q + 1;
+    if (r < nblk) {
+        const uint4* src = reinterpret_cast<const uint4*>(keys + (size_t)r * TM_RUN) + lane;
+        n0 = src[0]; n1 = src[64]; n2 = src[128]; n3 = src[192];
+    }
+    int par = 0;
+    while (r < nblk) {                                  // wave-uniform
+        uint32_t* s = s_run[wave][par];
+        uint4* dst = reinterpret_cast<uint4*>(s) + lane;
+        dst[0] = n0; dst[64] = n1; dst[128] = n2; dst[192] = n3;
+        q += stride;
+        const int rn = q < blk ? q : q + 1;
+        if (rn < nblk) {
+            const uint4* src = reinterpret_cast<const uint4*>(keys + (size_t)rn * TM_RUN) + lane;
+            n0 = src[0]; n1 = src[64]; n2 = src[128]; n3 = src[192];
+        }
+        __builtin_amdgcn_wave_barrier();                // LDS serves a wave's accesses in order
+        if (r < blk) tm_count<true>(s, own, cnt);       // wave-uniform
+        else tm_count<false>(s, own, cnt);
+        __builtin_amdgcn_wave_barrier();
+        par ^= 1;
+        r = rn;
+    }
+    // the four waves' counts of an element meet in LDS; thread t then speaks for elements 4t .. 4t+3
+    __syncthreads();
+    uint32_t* part = &s_run[0][0][0];                   // [TM_WAVES][TM_RUN]
+#pragma unroll
+    for (int it = 0; it < L; ++it) part[wave * TM_RUN + lane * L + it] = cnt[it];
+    __syncthreads();
+    uint32_t place[TM_PER_THREAD];
+#pragma unroll
+    for (int it = 0; it < TM_PER_THREAD; ++it) {
+        const int e = tid * TM_PER_THREAD + it;
+        place[it] = 0;
+#pragma unroll
+        for (int w = 0; w < TM_WAVES; ++w) place[it] += part[w * TM_RUN + e];
+    }
+    if (nsplit > 1) {
+        // Counts go to memory as device-scope atomic stores (served at the coherent point, past
+        // the per-XCD L2s) and have completed (vmcnt) before this workgroup is counted as
+        // arrived; the last one reads all of them the same way.
+        int* mine = reinterpret_cast<int*>(ws.part + ((run0 + blk) * nsplit + split) * TM_RUN);
+#pragma unroll
+        for (int it = 0; it < TM_PER_THREAD; ++it)
+            __hip_atomic_store(mine + tid * TM_PER_THREAD + it, (int)place[it], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0)
+            s_last = __hip_atomic_fetch_add(ws.arrived + run0 + blk, 1, __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_AGENT) == nsplit - 1;
+        __syncthreads();
+        if (!s_last) return;                            // workgroup-uniform
+        const int* all = reinterpret_cast<const int*>(ws.part + (run0 + blk) * nsplit * TM_RUN);
+#pragma unroll
+        for (int it = 0; it < TM_PER_THREAD; ++it) {
+            place[it] = 0;
+            for (int sp = 0; sp < nsplit; ++sp)
+                place[it] += (uint32_t)__hip_atomic_load(all + sp * TM_RUN + tid * TM_PER_THREAD + it,
+                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < TM_PER_THREAD; ++it) {
+        place[it] += tid * TM_PER_THREAD + it;
+        live[it] = live[it] && (int)place[it] < out.K;
+    }
+#pragma unroll
+    for (int it = 0; it < TM_PER_THREAD; ++it) {
+        if (!live[it]) continue;
+        const size_t o = (size_t)b * out.K + place[it];
+        out.top_idx[o] = idx[it];
+        out.top_scores[o] = sc[it];
+        if (out.cand) out.cand[o] = decode_box(an[it], dl[it], false);
+    }
 }
 
 }  // namespace frcnn
@@ -184,11 +456,37 @@ using namespace frcnn;
 
 static size_t ts_align(size_t v) { return (v + 255) & ~(size_t)255; }
 
-// workspace = keys [2][B][N] u32 | idx [2][B][N] i32 | hist [B][nblk][256] u32
+// sorted-runs form: workgroups that share the other runs of a run (every wave gets one or two)
+static int tm_nsplit(int nblk) {
+    const int want = (nblk - 1 + TM_WAVES - 1) / TM_WAVES;
+    return want < 1 ? 1 : want > TM_MAX_SPLIT ? TM_MAX_SPLIT : want;
+}
+static bool tm_wanted(int B, int nblk) {
+    long long max_runs = tuning(TUNE_TOPK_MERGE_MAX_RUNS);
+    if (max_runs == TUNE_UNSET) max_runs = TM_DEFAULT_MAX_RUNS;
+    return nblk <= TM_MAX_RUNS_PER_IMAGE && (long long)B * nblk <= max_runs && B <= 65535;
+}
+// keys | idx | partial counts | arrival counters
+static size_t tm_bytes(int B, int nblk) {
+    const size_t runs = (size_t)B * nblk;
+    return 2 * ts_align(runs * TM_RUN * 4) + ts_align(runs * tm_nsplit(nblk) * TM_RUN * 4) +
+           ts_align(runs * 4);
+}
+
+// radix passes: keys [2][B][N] u32 | idx [2][B][N] i32 | hist [B][nblk][256] u32; the sorted-runs
+// form lays its own buffers over the same bytes
+static size_t ts_radix_bytes(int B, int N) {
+    const size_t nblk = ((size_t)N + TS_BLK - 1) / TS_BLK;
+    return 4 * ts_align((size_t)B * N * 4) + ts_align((size_t)B * nblk * 256 * 4);
+}
+
 extern "C" size_t frcnn_topk_sort_workspace_bytes(int B, int N) {
     if (B <= 0 || N <= 0) return 0;
     const size_t nblk = ((size_t)N + TS_BLK - 1) / TS_BLK;
-    return 4 * ts_align((size_t)B * N * 4) + ts_align((size_t)B * nblk * 256 * 4);
+    const size_t radix = ts_radix_bytes(B, N);
+    const size_t runs = nblk <= (size_t)TM_MAX_RUNS_PER_IMAGE && tm_wanted(B, (int)nblk)
+                            ? tm_bytes(B, (int)nblk) : 0;
+    return radix > runs ? radix : runs;
 }
 
 extern "C" int frcnn_topk_sort(const float* scores, int B, int N, int K, const float* anchors,
@@ -200,8 +498,10 @@ extern "C" int frcnn_topk_sort(const float* scores, int B, int N, int K, const f
     const bool fuse = anchors && deltas;
     if ((anchors != nullptr) != (deltas != nullptr)) return FRCNN_E_BADARG;
     if (fuse && !cand_boxes) return FRCNN_E_BADARG;
-    if (!workspace || workspace_bytes < frcnn_topk_sort_workspace_bytes(B, N)) return FRCNN_E_WORKSPACE;
-    if (reinterpret_cast<uintptr_t>(workspace) & 3u) return FRCNN_E_BADARG;
+    // what the radix passes need always does; the sorted-runs form runs when there is room for it
+    // (a tuning value changed after the caller sized the workspace does not fail the call)
+    if (!workspace || workspace_bytes < ts_radix_bytes(B, N)) return FRCNN_E_WORKSPACE;
+    if (reinterpret_cast<uintptr_t>(workspace) & 15u) return FRCNN_E_BADARG;
     if (B > 65535 || (long long)B * N > 0x7FFFFFFFll) return FRCNN_E_UNSUPPORTED;
     const int nblk = (N + TS_BLK - 1) / TS_BLK;
     char* ws = reinterpret_cast<char*>(workspace);
@@ -212,17 +512,33 @@ extern "C" int frcnn_topk_sort(const float* scores, int B, int N, int K, const f
     uint32_t* hist = reinterpret_cast<uint32_t*>(ws + 4 * plane);
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)((long long)nblk * B)), block(64);
+    const TsOut out{K, reinterpret_cast<const float4*>(anchors), reinterpret_cast<const float4*>(deltas),
+                    top_scores, top_idx, fuse ? reinterpret_cast<float4*>(cand_boxes) : nullptr};
+    if (tm_wanted(B, nblk) && workspace_bytes >= tm_bytes(B, nblk)) {
+        const size_t runs = (size_t)B * nblk;
+        const int nsplit = tm_nsplit(nblk);
+        TmWorkspace tw;
+        char* p = ws;
+        tw.keys = reinterpret_cast<uint32_t*>(p);
+        p += ts_align(runs * TM_RUN * 4);
+        tw.idx = reinterpret_cast<int32_t*>(p);
+        p += ts_align(runs * TM_RUN * 4);
+        tw.part = reinterpret_cast<uint32_t*>(p);
+        p += ts_align(runs * nsplit * TM_RUN * 4);
+        tw.arrived = reinterpret_cast<int*>(p);
+        FRCNN_LAUNCH(tm_runs_kernel, dim3(nblk, B), dim3(TM_THREADS), 0, st, scores, N, nblk, tw);
+        FRCNN_LAUNCH(tm_rank_kernel, dim3(nblk, nsplit, B), dim3(TM_THREADS), 0, st, scores, N, nblk,
+                     nsplit, tw, out);
+        return FRCNN_OK;
+    }
 #define TS_PASS(P, KIN, IIN, KOUT, IOUT)                                                          \
     FRCNN_LAUNCH(ts_hist_kernel<P>, grid, block, 0, st, scores, KIN, N, nblk, B, hist);           \
     FRCNN_LAUNCH(ts_scatter_kernel<P>, grid, block, 0, st, scores, KIN, IIN, N, nblk, B, hist, KOUT, \
-                 IOUT)
+                 IOUT, out)
     TS_PASS(0, (const uint32_t*)nullptr, (const int32_t*)nullptr, keys[0], idx[0]);
     TS_PASS(1, keys[0], idx[0], keys[1], idx[1]);
     TS_PASS(2, keys[1], idx[1], keys[0], idx[0]);
-    TS_PASS(3, keys[0], idx[0], keys[1], idx[1]);
+    TS_PASS(3, keys[0], idx[0], (uint32_t*)nullptr, (int32_t*)nullptr);
 #undef TS_PASS
-    FRCNN_LAUNCH(ts_gather_kernel, dim3((K + 63) / 64, B), dim3(64), 0, st, scores, idx[1], N, K,
-                 reinterpret_cast<const float4*>(anchors), reinterpret_cast<const float4*>(deltas),
-                 top_scores, top_idx, fuse ? reinterpret_cast<float4*>(cand_boxes) : nullptr);
     return FRCNN_OK;
 }

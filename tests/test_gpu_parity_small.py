@@ -132,6 +132,35 @@ def test_topk_sort_large_and_negative(dev):
         assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize("B,N,K", [(1, 20646, 12000), (2, 1000, 1000), (3, 63001, 50000), (5, 4097, 17),
+                                   (1, 64 * 1024, 64 * 1024), (4, 1025, 1025)])
+def test_topk_sort_routes_agree(dev, B, N, K):
+    """frcnn_topk_sort picks between the radix passes and the two-launch sorted-runs form by the
+    size of the call: both against the oracle, and against each other with the fused decode, on
+    scores with long runs of ties, both zeros and both signs."""
+    from objectdetection_amd import _lib, ops
+    rng = np.random.default_rng(B * 1000 + N)
+    s = rng.standard_normal((B, N)).astype(np.float32)
+    s[0, : N // 3] = np.float32(0.5)
+    s[-1, ::5] = s[-1, 1]
+    s[-1, 2], s[-1, 3] = np.float32(-0.0), np.float32(0.0)
+    anc = np.sort(rng.random((N, 2, 2)).astype(np.float32), axis=1).transpose(0, 2, 1).reshape(N, 4)
+    anc = np.ascontiguousarray(anc[:, [0, 2, 1, 3]])
+    dl = (rng.standard_normal((B, N, 4)) * 0.3).astype(np.float32)
+    rv, ri = O.top_k(s, K)
+    got = {}
+    try:
+        for route, runs in (("radix", 0), ("runs", 1 << 30)):
+            _lib.set_tuning("topk_merge_max_runs", runs)
+            got[route] = ops.topk(T(s, dev), K, T(anc, dev), T(dl, dev), method="sort")
+            np.testing.assert_array_equal(got[route][1].cpu().numpy(), ri, err_msg=route)
+            np.testing.assert_array_equal(got[route][0].cpu().numpy(), rv, err_msg=route)
+    finally:
+        _lib.set_tuning("topk_merge_max_runs", None)
+    for x, y in zip(got["radix"], got["runs"]):
+        assert torch.equal(x, y)
+
+
 def test_proposals_bit_exact_given_boxes(dev, ref_inputs):
     """NMS keep list on identical box inputs (device-decoded boxes fed to the oracle)."""
     from objectdetection_amd.module.model import propose

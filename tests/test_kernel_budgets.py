@@ -72,6 +72,6 @@ def test_target_kernels_fit_beside_a_band_workgroup(budgets):
         k = budgets[name]
         assert k["vgpr"] <= 128 and k["lds"] <= 9 * 1024 and k["scratch"] == 0, (name, k)
     for name in ("iou_assign_kernel", "label_proposals_kernel", "ts_hist_kernel<0>",
-                 "ts_scatter_kernel<0>", "ts_gather_kernel"):
+                 "ts_scatter_kernel<0>", "ts_scatter_kernel<3>"):
         k = budgets[name]
         assert k["vgpr"] <= 64 and k["scratch"] == 0, (name, k)

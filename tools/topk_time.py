@@ -9,7 +9,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
-from objectdetection_amd import ops  # noqa: E402
+from objectdetection_amd import _lib, ops  # noqa: E402
 
 dev = torch.device("cuda:0")
 cfg = bench.workload_cfg()
@@ -17,9 +17,10 @@ anchor = ops.anchors(cfg.H, cfg.W, cfg.scales, cfg.ratios, cfg.base_w, cfg.base_
 for B in (1, 4, 16, 64):
     fmap, score, coord, gt, label = bench.make_inputs(cfg, B, 8, dev, 1000)
     s, d = score.reshape(B, -1), coord.reshape(B, -1, 4)
-    ws = torch.empty(ops.topk_sort_workspace_bytes(B, s.shape[1]), dtype=torch.uint8, device=dev)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for method in ("lds", "sort"):
+    for method, runs in (("lds", None), ("sort", 0), ("sort", 1 << 30)):
+        _lib.set_tuning("topk_merge_max_runs", runs)
+        ws = torch.empty(ops.topk_sort_workspace_bytes(B, s.shape[1]), dtype=torch.uint8, device=dev)
         ts = []
         for _ in range(8):
             e0.record()
@@ -27,4 +28,6 @@ for B in (1, 4, 16, 64):
             e1.record()
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1))
-        print(f"B={B} {method}: min {min(ts)*1e3:.1f} us  mean {np.mean(ts[2:])*1e3:.1f} us")
+        name = method if runs is None else ("radix passes" if runs == 0 else "sorted runs")
+        print(f"B={B} {name}: min {min(ts)*1e3:.1f} us  mean {np.mean(ts[2:])*1e3:.1f} us")
+    _lib.set_tuning("topk_merge_max_runs", None)
