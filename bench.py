@@ -159,7 +159,7 @@ def single_image(cfg, C, device, seed=4242):
     """One image through the inference stages (the reference's per-epoch check runs one image,
     model_train.py:741-743): whole-path latency as plain launches and as one HIP graph replay,
     and the stages alone.  HIP events, idle chip, outside the timed region."""
-    from objectdetection_amd import ops
+    from objectdetection_amd import _lib, ops
     from objectdetection_amd.pipeline import RegionProposalPath
     fmap, score, coord, _, _ = make_inputs(cfg, 1, C, device, seed=seed)
     path = RegionProposalPath(cfg, 1, C, device, train=False, depth=1)
@@ -170,6 +170,10 @@ def single_image(cfg, C, device, seed=4242):
     a = path.anchor.reshape(-1, 4)
     topk_ms = timed_alone(lambda: ops.topk(score.reshape(1, -1), cfg.pre_k, a, coord, "sort",
                                            workspace=path.topk_ws), device, reps=40, skip=10)
+    _lib.set_tuning("topk_merge_max_runs", 0)
+    radix_ms = timed_alone(lambda: ops.topk(score.reshape(1, -1), cfg.pre_k, a, coord, "sort",
+                                            workspace=path.topk_ws), device, reps=40, skip=10)
+    _lib.set_tuning("topk_merge_max_runs", None)
     nms_call = ops.nms_fused if path.nms == "fused" else ops.nms
     nms_ms = timed_alone(lambda: nms_call(path.cand, cfg.nms_thr, cfg.post_n, workspace=path.nms_ws),
                          device, reps=40, skip=10)
@@ -180,6 +184,8 @@ def single_image(cfg, C, device, seed=4242):
                          device, reps=40, skip=10)
     return dict(latency_b1_ms=min(plain, replay), latency_b1_plain_launches_ms=plain,
                 latency_b1_graph_replay_ms=replay, topk_us_single_image=topk_ms * 1e3,
+                topk_route_single_image=ops.topk_sort_route(1, score.numel(), path.topk_ws.numel()),
+                topk_us_single_image_radix_passes=radix_ms * 1e3,
                 nms_us_single_image=nms_ms * 1e3, nms_route_single_image=path.nms,
                 nms_us_single_image_chunked=chunked_ms * 1e3, roi_us_single_image=roi_ms * 1e3,
                 kept=int(path.keep_count[0]),

@@ -160,6 +160,9 @@ int frcnn_topk(const float* scores, int B, int N, int K,
  * other blocks of its image.  workspace: frcnn_topk_sort_workspace_bytes(B,N) bytes (about
  * 16 bytes per score), 256-byte aligned. */
 size_t frcnn_topk_sort_workspace_bytes(int B, int N);
+/* 1 if a call of this size with this much workspace takes the two-launch sorted-runs form, 0 if
+ * the radix passes (no counterpart in the reference; for tests and bench lines). */
+int frcnn_topk_sort_plan(int B, int N, size_t workspace_bytes);
 int frcnn_topk_sort(const float* scores, int B, int N, int K,
                     const float* anchors, const float* deltas,
                     float* top_scores, int32_t* top_idx, float* cand_boxes,

@@ -51,6 +51,7 @@ _SIGS = {
     "frcnn_decode_clip": (_i, [_p, _p, _i, _i64, _i, _p, _p]),
     "frcnn_topk": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
     "frcnn_topk_sort_workspace_bytes": (_sz, [_i, _i]),
+    "frcnn_topk_sort_plan": (_i, [_i, _i, _sz]),
     "frcnn_topk_sort": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "frcnn_nms_workspace_bytes": (_sz, [_i, _i, _i]),
     "frcnn_nms": (_i, [_p, _i, _i, _f, _i, _p, _p, _p, _p, _sz, _p]),

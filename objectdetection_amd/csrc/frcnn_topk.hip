@@ -327,7 +327,9 @@ __global__ void __launch_bounds__(TM_THREADS)
 tm_rank_kernel(const float* __restrict__ scores, int N, int nblk, int nsplit, TmWorkspace ws,
                TsOut out) {
     constexpr int L = TM_PER_LANE;
-    __shared__ __attribute__((aligned(16))) uint32_t s_run[TM_WAVES][2][TM_RUN];    // 32 KB
+    // one staging buffer per wave: LDS serves a wave's accesses in order, so the next run's words
+    // land behind the last search's reads.  16 KB: fits beside a band-resident RoI workgroup.
+    __shared__ __attribute__((aligned(16))) uint32_t s_run[TM_WAVES][TM_RUN];
     __shared__ int s_last;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int blk = blockIdx.x, split = blockIdx.y, b = blockIdx.z;
@@ -345,27 +347,6 @@ tm_rank_kernel(const float* __restrict__ scores, int N, int nblk, int nsplit, Tm
 #pragma unroll
         for (int it = 0; it < L; ++it) cnt[it] = 0;
     }
-    // what the outputs of elements 4 tid .. 4 tid + 3 will need, asked for now: the workgroup that
-    // arrives last writes them, and which one that is shows only at the end
-    const size_t base = (size_t)b * N;
-    int idx[TM_PER_THREAD];
-    bool live[TM_PER_THREAD];
-    float sc[TM_PER_THREAD];
-    float4 an[TM_PER_THREAD], dl[TM_PER_THREAD];
-    {
-        const uint4 i4 = reinterpret_cast<const uint4*>(ws.idx + (run0 + blk) * TM_RUN)[tid];
-        const uint32_t mine_idx[TM_PER_THREAD] = {i4.x, i4.y, i4.z, i4.w};
-#pragma unroll
-        for (int it = 0; it < TM_PER_THREAD; ++it) {
-            live[it] = mine_idx[it] != 0xFFFFFFFFu;    // a filler's index (no score has it: N < 2^31)
-            idx[it] = live[it] ? (int)mine_idx[it] : 0;
-            sc[it] = scores[base + idx[it]];
-            if (out.cand) {
-                an[it] = out.anchors[idx[it]];
-                dl[it] = out.deltas[base + idx[it]];
-            }
-        }
-    }
     // this wave's share of the other runs: every (TM_WAVES * nsplit)-th of the runs that are not
     // blk.  The next one is on its way from memory while this one is searched.
     const int stride = TM_WAVES * nsplit;
@@ -378,9 +359,8 @@ tm_rank_kernel(const float* __restrict__ scores, int N, int nblk, int nsplit, Tm
         const uint4* src = reinterpret_cast<const uint4*>(keys + (size_t)r * TM_RUN) + lane;
         n0 = src[0]; n1 = src[64]; n2 = src[128]; n3 = src[192];
     }
-    int par = 0;
     while (r < nblk) {                                  // wave-uniform
-        uint32_t* s = s_run[wave][par];
+        uint32_t* s = s_run[wave];
         uint4* dst = reinterpret_cast<uint4*>(s) + lane;
         dst[0] = n0; dst[64] = n1; dst[128] = n2; dst[192] = n3;
         q += stride;
@@ -389,16 +369,15 @@ tm_rank_kernel(const float* __restrict__ scores, int N, int nblk, int nsplit, Tm
             const uint4* src = reinterpret_cast<const uint4*>(keys + (size_t)rn * TM_RUN) + lane;
             n0 = src[0]; n1 = src[64]; n2 = src[128]; n3 = src[192];
         }
-        __builtin_amdgcn_wave_barrier();                // LDS serves a wave's accesses in order
+        __builtin_amdgcn_wave_barrier();
         if (r < blk) tm_count<true>(s, own, cnt);       // wave-uniform
         else tm_count<false>(s, own, cnt);
         __builtin_amdgcn_wave_barrier();
-        par ^= 1;
         r = rn;
     }
     // the four waves' counts of an element meet in LDS; thread t then speaks for elements 4t .. 4t+3
     __syncthreads();
-    uint32_t* part = &s_run[0][0][0];                   // [TM_WAVES][TM_RUN]
+    uint32_t* part = &s_run[0][0];                      // [TM_WAVES][TM_RUN]
 #pragma unroll
     for (int it = 0; it < L; ++it) part[wave * TM_RUN + lane * L + it] = cnt[it];
     __syncthreads();
@@ -435,10 +414,24 @@ tm_rank_kernel(const float* __restrict__ scores, int N, int nblk, int nsplit, Tm
                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    const size_t base = (size_t)b * N;
+    const uint4 i4 = reinterpret_cast<const uint4*>(ws.idx + (run0 + blk) * TM_RUN)[tid];
+    const uint32_t mine_idx[TM_PER_THREAD] = {i4.x, i4.y, i4.z, i4.w};
+    int idx[TM_PER_THREAD];
+    bool live[TM_PER_THREAD];
+    float sc[TM_PER_THREAD];
+    float4 an[TM_PER_THREAD], dl[TM_PER_THREAD];
 #pragma unroll
     for (int it = 0; it < TM_PER_THREAD; ++it) {
         place[it] += tid * TM_PER_THREAD + it;
-        live[it] = live[it] && (int)place[it] < out.K;
+        // a filler carries index 0xFFFFFFFF (no score has it: N < 2^31)
+        live[it] = (int)place[it] < out.K && mine_idx[it] != 0xFFFFFFFFu;
+        idx[it] = live[it] ? (int)mine_idx[it] : 0;
+        sc[it] = scores[base + idx[it]];
+        if (out.cand) {
+            an[it] = out.anchors[idx[it]];
+            dl[it] = out.deltas[base + idx[it]];
+        }
     }
 #pragma unroll
     for (int it = 0; it < TM_PER_THREAD; ++it) {
@@ -489,6 +482,12 @@ extern "C" size_t frcnn_topk_sort_workspace_bytes(int B, int N) {
     return radix > runs ? radix : runs;
 }
 
+extern "C" int frcnn_topk_sort_plan(int B, int N, size_t workspace_bytes) {
+    if (B <= 0 || N <= 0) return 0;
+    const int nblk = (N + TS_BLK - 1) / TS_BLK;
+    return tm_wanted(B, nblk) && workspace_bytes >= tm_bytes(B, nblk) ? 1 : 0;
+}
+
 extern "C" int frcnn_topk_sort(const float* scores, int B, int N, int K, const float* anchors,
                                const float* deltas, float* top_scores, int32_t* top_idx,
                                float* cand_boxes, void* workspace, size_t workspace_bytes,
@@ -514,7 +513,7 @@ extern "C" int frcnn_topk_sort(const float* scores, int B, int N, int K, const f
     const dim3 grid((unsigned)((long long)nblk * B)), block(64);
     const TsOut out{K, reinterpret_cast<const float4*>(anchors), reinterpret_cast<const float4*>(deltas),
                     top_scores, top_idx, fuse ? reinterpret_cast<float4*>(cand_boxes) : nullptr};
-    if (tm_wanted(B, nblk) && workspace_bytes >= tm_bytes(B, nblk)) {
+    if (frcnn_topk_sort_plan(B, N, workspace_bytes)) {
         const size_t runs = (size_t)B * nblk;
         const int nsplit = tm_nsplit(nblk);
         TmWorkspace tw;

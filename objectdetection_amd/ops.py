@@ -155,6 +155,14 @@ def topk_sort_workspace_bytes(B: int, N: int) -> int:
     return int(lib.frcnn_topk_sort_workspace_bytes(B, N))
 
 
+def topk_sort_route(B: int, N: int, workspace_bytes: Optional[int] = None) -> str:
+    """Which form frcnn_topk_sort takes for a call of this size (frcnn_topk_sort_plan): "sorted runs"
+    (two launches, a few images) or "radix passes"."""
+    if workspace_bytes is None:
+        workspace_bytes = topk_sort_workspace_bytes(B, N)
+    return "sorted runs" if lib.frcnn_topk_sort_plan(B, N, workspace_bytes) else "radix passes"
+
+
 def topk(scores: torch.Tensor, k: int, anchor_flat: Optional[torch.Tensor] = None,
          deltas: Optional[torch.Tensor] = None, method: str = "auto",
          workspace: Optional[torch.Tensor] = None):

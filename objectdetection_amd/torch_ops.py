@@ -45,7 +45,7 @@ OP_ENTRY_POINTS = {
 HELPER_ENTRY_POINTS = (
     "frcnn_abi_version", "frcnn_status_string", "frcnn_set_tuning", "frcnn_get_tuning",
     "frcnn_topk_sort_workspace_bytes", "frcnn_nms_workspace_bytes", "frcnn_roi_fwd_workspace_bytes",
-    "frcnn_roi_fwd_plan",
+    "frcnn_roi_fwd_plan", "frcnn_topk_sort_plan",
     # stream-ordered halves / allocation-free variants used by RegionProposalPath and serving
     # loops directly; as operators they would be the ones above
     "frcnn_roi_fwd_prepare", "frcnn_roi_crop_pool_fwd_prepared", "frcnn_nms_static",

@@ -85,6 +85,37 @@ def test_no_entry_point_reads_the_environment():
             assert src.count("getenv(") == 1
 
 
+def test_topk_sort_plan_and_workspace():
+    """Which form frcnn_topk_sort takes is host logic: sorted runs + ranks (two launches) for calls
+    of up to topk_merge_max_runs blocks of 1,024 scores and at most 64 blocks per image, when the
+    workspace has room for it; the radix passes otherwise.  The workspace size covers the form
+    the current tuning selects and never less than the radix passes need."""
+    from objectdetection_amd import _lib, ops
+    L = _lib.lib
+    _lib.set_tuning("topk_merge_max_runs", None)
+    N = 37 * 62 * 9
+    ws = lambda B, n: int(L.frcnn_topk_sort_workspace_bytes(B, n))
+    assert L.frcnn_topk_sort_plan(1, N, ws(1, N)) == 1            # 21 blocks
+    assert L.frcnn_topk_sort_plan(12, N, ws(12, N)) == 1          # 252 blocks
+    assert L.frcnn_topk_sort_plan(13, N, ws(13, N)) == 0          # 273 > 256
+    assert L.frcnn_topk_sort_plan(64, N, ws(64, N)) == 0
+    assert L.frcnn_topk_sort_plan(1, 100000, ws(1, 100000)) == 0  # 98 blocks in one image
+    assert L.frcnn_topk_sort_plan(1, N, 0) == 0 and L.frcnn_topk_sort_plan(0, N, 1 << 30) == 0
+    radix_only = ws(64, N)
+    try:
+        _lib.set_tuning("topk_merge_max_runs", 0)
+        assert L.frcnn_topk_sort_plan(1, N, 1 << 30) == 0
+        small = ws(1, N)
+        _lib.set_tuning("topk_merge_max_runs", 1 << 30)
+        assert ws(1, N) > small                                   # partial counts need more room
+        assert L.frcnn_topk_sort_plan(1, N, small) == 0           # sized before the change: radix
+        assert L.frcnn_topk_sort_plan(64, N, ws(64, N)) == 1 and ws(64, N) > radix_only
+        assert ops.topk_sort_route(64, N) == "sorted runs"
+    finally:
+        _lib.set_tuning("topk_merge_max_runs", None)
+    assert ops.topk_sort_route(64, N) == "radix passes" and ops.topk_sort_route(1, N) == "sorted runs"
+
+
 def test_roi_forward_plan_and_prepare_argument_checks():
     """Which RoI forward kernel a call gets is host logic (no launch): the band-resident kernel
     from 768 workgroups (B * C/32 * bands) and 1,024 RoIs per image on, the per-RoI one below;

@@ -152,6 +152,8 @@ def test_topk_sort_routes_agree(dev, B, N, K):
     try:
         for route, runs in (("radix", 0), ("runs", 1 << 30)):
             _lib.set_tuning("topk_merge_max_runs", runs)
+            # the route that is asked for is the one that runs (up to 64 blocks per image)
+            assert ops.topk_sort_route(B, N) == ("radix passes" if route == "radix" else "sorted runs")
             got[route] = ops.topk(T(s, dev), K, T(anc, dev), T(dl, dev), method="sort")
             np.testing.assert_array_equal(got[route][1].cpu().numpy(), ri, err_msg=route)
             np.testing.assert_array_equal(got[route][0].cpu().numpy(), rv, err_msg=route)

@@ -71,6 +71,11 @@ def test_target_kernels_fit_beside_a_band_workgroup(budgets):
     for name in ("rpn_sample_kernel<256,256>", "sample_proposals_kernel<256,256>"):
         k = budgets[name]
         assert k["vgpr"] <= 128 and k["lds"] <= 9 * 1024 and k["scratch"] == 0, (name, k)
+    # the two-launch top-k: 256-thread workgroups that fit the same 128 registers per lane and
+    # 23 KB of LDS
+    for name in ("tm_runs_kernel", "tm_rank_kernel"):
+        k = budgets[name]
+        assert k["vgpr"] <= 128 and k["lds"] <= 17 * 1024 and k["scratch"] == 0, (name, k)
     for name in ("iou_assign_kernel", "label_proposals_kernel", "ts_hist_kernel<0>",
                  "ts_scatter_kernel<0>", "ts_scatter_kernel<3>"):
         k = budgets[name]
