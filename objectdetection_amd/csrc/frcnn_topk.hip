@@ -255,7 +255,9 @@ __device__ __forceinline__ void tm_sort_block(unsigned long long (&v)[TM_PER_THR
                 }
 #pragma unroll
                 for (int it = 0; it < T; ++it) {
-                    const bool take = keep_min ? o[it] < v[it] : o[it] > v[it];
+                    // one compare and no branch: elements are distinct (equal fillers swap for
+                    // themselves)
+                    const bool take = (o[it] < v[it]) == keep_min;
                     v[it] = take ? o[it] : v[it];
                 }
             } else {                                    // partner: register it ^ j of this thread
@@ -265,7 +267,7 @@ __device__ __forceinline__ void tm_sort_block(unsigned long long (&v)[TM_PER_THR
                     const int p = it | j;
                     const bool asc = (((tid * T) | it) & k) == 0;
                     const unsigned long long a = v[it], c = v[p];
-                    const bool sw = asc ? a > c : a < c;
+                    const bool sw = (a > c) == asc;
                     v[it] = sw ? c : a;
                     v[p] = sw ? a : c;
                 }
