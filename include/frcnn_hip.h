@@ -158,7 +158,9 @@ int frcnn_topk(const float* scores, int B, int N, int K,
  * "topk_merge_max_runs") takes two launches instead: one wave sorts each block of 1,024
  * scores, then every score's place is its place in its block plus the smaller scores of all
  * other blocks of its image.  workspace: frcnn_topk_sort_workspace_bytes(B,N) bytes (about
- * 16 bytes per score), 256-byte aligned. */
+ * 16 bytes per score; up to 30 for a call that takes the two-launch form under the tuning
+ * value in force when the size is asked for), 16-byte aligned.  A workspace that only covers
+ * the radix passes is always accepted: the call then takes them. */
 size_t frcnn_topk_sort_workspace_bytes(int B, int N);
 /* 1 if a call of this size with this much workspace takes the two-launch sorted-runs form, 0 if
  * the radix passes (no counterpart in the reference; for tests and bench lines). */
