@@ -133,7 +133,8 @@ def test_topk_sort_large_and_negative(dev):
 
 
 @pytest.mark.parametrize("B,N,K", [(1, 20646, 12000), (2, 1000, 1000), (3, 63001, 50000), (5, 4097, 17),
-                                   (1, 64 * 1024, 64 * 1024), (4, 1025, 1025)])
+                                   (1, 64 * 1024, 64 * 1024), (4, 1025, 1025), (1, 1, 1), (3, 1024, 1024),
+                                   (2, 1023, 5), (1, 2049, 2049), (7, 9, 9)])
 def test_topk_sort_routes_agree(dev, B, N, K):
     """frcnn_topk_sort picks between the radix passes and the two-launch sorted-runs form by the
     size of the call: both against the oracle, and against each other with the fused decode, on
@@ -142,8 +143,9 @@ def test_topk_sort_routes_agree(dev, B, N, K):
     rng = np.random.default_rng(B * 1000 + N)
     s = rng.standard_normal((B, N)).astype(np.float32)
     s[0, : N // 3] = np.float32(0.5)
-    s[-1, ::5] = s[-1, 1]
-    s[-1, 2], s[-1, 3] = np.float32(-0.0), np.float32(0.0)
+    if N >= 4:
+        s[-1, ::5] = s[-1, 1]
+        s[-1, 2], s[-1, 3] = np.float32(-0.0), np.float32(0.0)
     anc = np.sort(rng.random((N, 2, 2)).astype(np.float32), axis=1).transpose(0, 2, 1).reshape(N, 4)
     anc = np.ascontiguousarray(anc[:, [0, 2, 1, 3]])
     dl = (rng.standard_normal((B, N, 4)) * 0.3).astype(np.float32)
