@@ -167,7 +167,9 @@ def topk(scores: torch.Tensor, k: int, anchor_flat: Optional[torch.Tensor] = Non
          deltas: Optional[torch.Tensor] = None, method: str = "auto",
          workspace: Optional[torch.Tensor] = None):
     """scores [B,N] -> (values [B,k], idx [B,k] i32, cand_boxes [B,k,4] | None).
-    method: "lds" (frcnn_topk, k <= 16384), "sort" (frcnn_topk_sort, any k) or "auto"."""
+    method: "lds" (frcnn_topk, k <= 16384), "sort" (frcnn_topk_sort, any k) or "auto" (= "sort":
+    it is the faster one at every size measured -- one image 36 us against 250, 64 images 0.12 ms
+    against 0.27 -- also when its workspace has to come from torch's caching allocator)."""
     s = _cont(scores, "scores", torch.float32)
     if s.dim() != 2:
         raise ValueError("scores must be [B,N]")
@@ -182,7 +184,7 @@ def topk(scores: torch.Tensor, k: int, anchor_flat: Optional[torch.Tensor] = Non
             raise ValueError("anchors / deltas do not match scores")
         cand = torch.empty((B, k, 4), dtype=torch.float32, device=s.device)
     if method == "auto":
-        method = "lds" if k <= 16384 and workspace is None else "sort"
+        method = "sort"
     with torch.cuda.device(s.device):
         if method == "lds":
             check("frcnn_topk", lib.frcnn_topk(_ptr(s), B, N, k, _ptr(a), _ptr(d), _ptr(vals),
